@@ -1,0 +1,195 @@
+/*
+ * sparsefusion_hip.h -- C ABI of libsparsefusion_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for SparseFusion's LiDAR hot path: point-cloud voxelization and the
+ * SparseEncoder sparse-3D-convolution backbone.  Plain pointers and sizes only; every pointer
+ * named *_dev / points / voxels / ... is DEVICE memory owned by the caller (the library never
+ * allocates or frees device memory); `stream` is a hipStream_t passed as void*.  Functions
+ * return SF_OK (0) or a negative SF_ERR_* code; sf_last_error() describes the last failure of
+ * the calling thread.  Unless stated otherwise a call only enqueues work on `stream`.
+ *
+ * Row counts that are data dependent live in device memory: an argument pair
+ * (`const int *n_dev`, `int n_bound`) means "process *n_dev rows (read on the device when the
+ * kernel runs); n_bound is a host-known upper bound used for sizing grids and checking
+ * buffers".  n_dev may be NULL, then exactly n_bound rows are processed.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the upstream
+ * SparseFusion checkout).
+ */
+#ifndef SPARSEFUSION_HIP_H_
+#define SPARSEFUSION_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SF_OK 0
+#define SF_ERR_BAD_ARG (-1)   /* null pointer, bad size, unsupported parameter               */
+#define SF_ERR_WORKSPACE (-2) /* workspace / output buffer smaller than required             */
+#define SF_ERR_CAPACITY (-3)  /* coordinate key space does not fit 32 bits, or table overflow */
+#define SF_ERR_HIP (-4)       /* a HIP runtime call failed                                   */
+
+#define SF_API __attribute__((visibility("default")))
+
+/* Library version (major*10000 + minor*100 + patch). */
+SF_API int sf_version(void);
+/* Message for the last error returned on this thread ("" if none). */
+SF_API const char *sf_last_error(void);
+
+/* ------------------------------------------------------------------ voxelization ---- */
+
+/* Replaces voxel_layer.dynamic_voxelize (mmdet3d/ops/voxel/src/voxelization.cpp:8,
+ * voxelization.h:71-83; kernel voxelization_cuda.cu:24-61, CPU voxelization_cpu.cpp:7-41).
+ * points (n,f) f32 with xyz first -> coors (n,3) i32 (z,y,x); all three -1 for a point outside
+ * the range (as the CPU path does).  grid = round((hi-lo)/vs) in fp32. */
+SF_API int sf_dynamic_voxelize(const float *points, int n, int f, const float voxel_size[3],
+                               const float coors_range[6], int *coors, void *stream);
+
+/* Bytes of scratch sf_hard_voxelize needs for n points. */
+SF_API size_t sf_hard_voxelize_workspace(int n, int max_points);
+
+/* Replaces voxel_layer.hard_voxelize (voxelization.cpp:7, voxelization.h:51-69; GPU
+ * voxelization_cuda.cu:184-326, CPU voxelization_cpu.cpp:43-142) and, optionally, the
+ * HardSimpleVFE mean (mmdet3d/models/voxel_encoders/voxel_encoder.py:42-44) and the per-sample
+ * glue of detectors/sparsefusion.py:146-157.
+ *
+ * Semantics are the reference's sequential ones, bit for bit: voxels are numbered in order of
+ * their first point; a point that would open voxel number max_voxels stops the scan (it and
+ * every later point are dropped); each voxel keeps its first max_points points in point order.
+ *
+ *  voxels   (rows, max_points, f) f32 : rows [base, base+voxel_num) are written completely
+ *                                        (unused slots zero).  May be NULL (skip).
+ *  coors    (rows, coors_stride) i32   : coors_stride 3 -> (z,y,x); 4 -> (batch_idx,z,y,x).
+ *  num_points_per_voxel (rows) i32     : may be NULL.
+ *  mean     (rows, mean_stride) f32    : per-voxel mean of the first mean_features point
+ *                                        features, columns [mean_features, mean_stride) zero.
+ *                                        May be NULL.
+ *  row_count_dev : device int, in = base row of this sample, out = base + voxel_num, so that
+ *                  consecutive samples of a batch append without a host round trip.
+ *  rows_capacity : rows the four outputs hold; base + voxel_num beyond it is clipped and
+ *                  reported through *overflow_dev (if non-NULL, set to 1).
+ *  voxel_num_host: if non-NULL the stream is synchronised and this sample's voxel_num is
+ *                  returned (the reference's return value); NULL keeps the call asynchronous.
+ */
+SF_API int sf_hard_voxelize(const float *points, int n, int f, const float voxel_size[3],
+                            const float coors_range[6], int max_points, int max_voxels,
+                            float *voxels, int *coors, int coors_stride, int batch_idx,
+                            int *num_points_per_voxel, float *mean, int mean_features,
+                            int mean_stride, int *row_count_dev, int rows_capacity,
+                            int *overflow_dev, int *voxel_num_host, void *workspace,
+                            size_t workspace_bytes, void *stream);
+
+/* Replaces HardSimpleVFE.forward (mmdet3d/models/voxel_encoders/voxel_encoder.py:27-44) on an
+ * already materialised voxel tensor: out[v][k] = sum_s voxels[v][s][k] / num_points[v] for
+ * k < num_features, columns [num_features, out_stride) zero. */
+SF_API int sf_voxel_mean(const float *voxels, const int *num_points_per_voxel, const int *m_dev,
+                         int m_bound, int max_points, int f, int num_features, float *out,
+                         int out_stride, void *stream);
+
+/* ------------------------------------------------------------------ rulebook --------- */
+
+/* Slots (power of two) a coordinate hash table needs for up to n_bound distinct coordinates.
+ * A table is `capacity` uint32 keys plus `capacity` int32 values, both caller allocated. */
+SF_API int sf_hash_capacity(long long n_bound);
+
+/* Coordinate hash of the active set: indices (n,4) i32 (b,z,y,x) -> table mapping the linear
+ * index ((b*D+z)*H+y)*W+x to the row number (first occurrence wins for duplicate rows).
+ * Plays the role of the dense `gridOut` of spconv 1.x (mmdet3d/ops/spconv/include/spconv/
+ * spconv_ops.h:60-62, indice.cu.h:147-164 prepareSubMGridKernel) without B*D*H*W memory.
+ * keys/vals are (re)initialised here. */
+SF_API int sf_hash_build(const int *indices, const int *n_dev, int n_bound, const int shape[3],
+                         int batch, uint32_t *keys, int *vals, int capacity, int *overflow_dev,
+                         void *stream);
+
+/* Bytes of scratch sf_conv_output_set needs. */
+SF_API size_t sf_conv_output_set_workspace(int n_bound, int out_capacity);
+
+/* Output active set of a strided SparseConv3d: replaces the output half of
+ * getIndicePairsConv (include/spconv/geometry.h:144-194; GPU P1 + unique + P2,
+ * indice.cu.h:22-65,112-145).  Output rows come out in the CPU reference's first-touch order
+ * (inputs in row order, each input's outputs in getValidOutPos order, geometry.h:57-83).
+ *  out_keys/out_vals : hash of the OUTPUT set (coordinate -> output row), built here; it is
+ *                      the input table of the next layer.
+ *  outids (rows,4)   : (b,z,y,x) of every output row; *n_out_dev receives the row count. */
+SF_API int sf_conv_output_set(const int *indices, const int *n_dev, int n_bound, int batch,
+                              const int out_shape[3], const int ksize[3], const int stride[3],
+                              const int padding[3], uint32_t *out_keys, int *out_vals,
+                              int out_capacity, int *outids, int outids_rows, int *n_out_dev,
+                              int *overflow_dev, void *workspace, size_t workspace_bytes,
+                              void *stream);
+
+/* Neighbour table = the rulebook in output-major form: nbr[k*nbr_stride + o] is the input row
+ * that feeds output row o through kernel offset k = (kz*kH+ky)*kW+kx, or -1.  Same pairs as
+ * indicePairs/indiceNum of getIndicePairsSubM / getIndicePairsConv (geometry.h:247-297,
+ * :144-194): in = out*stride - padding + (kz,ky,kx).  For SubMConv3d pass outids = the input
+ * indices, stride 1, padding k/2 and identity_center=1 (centre offset pairs every row with
+ * itself, spconv_ops.h:300-303). */
+SF_API int sf_neighbor_table(const int *outids, const int *n_out_dev, int n_out_bound, int batch,
+                             const int in_shape[3], const int ksize[3], const int stride[3],
+                             const int padding[3], const uint32_t *in_keys, const int *in_vals,
+                             int in_capacity, int identity_center, int *nbr, int nbr_stride,
+                             void *stream);
+
+/* Bytes of scratch sf_export_indice_pairs needs. */
+SF_API size_t sf_export_indice_pairs_workspace(int K, int n_in);
+
+/* Neighbour table -> the reference's rulebook tensors: indice_pairs (K,2,n_in) i32 padded with
+ * -1 and indice_num (K) i32, exactly the layout of sparse_conv_ext.get_indice_pairs_3d
+ * (mmdet3d/ops/spconv/src/all.cc:21-51, spconv_ops.h:55-59), pairs of each offset listed in
+ * ascending input-row order (the CPU reference's order, geometry.h:171-192). */
+SF_API int sf_export_indice_pairs(const int *nbr, int nbr_stride, int K, const int *n_out_dev,
+                                  int n_out_bound, int n_in, int *indice_pairs, int *indice_num,
+                                  void *workspace, size_t workspace_bytes, void *stream);
+
+/* The inverse: the reference's rulebook tensors (indice_pairs (K,2,L), indice_num (K), e.g. from
+ * the CPU path of get_indice_pairs) -> neighbour table nbr (K, nbr_stride), so that
+ * sf_sparse_conv_f32 can run from a rulebook in the reference's own format
+ * (the argument list of sparse_conv_ext.indice_conv_fp32, all.cc / ops.py:108-126). */
+SF_API int sf_indice_pairs_to_table(const int *indice_pairs, const int *indice_num, int K, int L,
+                                    int n_out, int *nbr, int nbr_stride, void *stream);
+
+/* ------------------------------------------------------------------ convolution ------ */
+
+/* Channel count a feature matrix must be padded to as conv INPUT (8, 16, 32, 64 or 128), or
+ * -1 if unsupported.  Output channels must be 16, 32, 64 or 128. */
+SF_API int sf_conv_padded_cin(int cin);
+
+/* Re-order filters (K, cin, cout) f32 [= spconv-1.x (kD,kH,kW,Cin,Cout) flattened,
+ * mmdet3d/ops/spconv/conv.py:98-99] into the MFMA fragment order the conv kernel streams.
+ * w_packed holds K * max(sf_conv_padded_cin(cin),16) * cout floats. */
+SF_API int sf_pack_filters_f32(const float *w_kio, int K, int cin, int cout, float *w_packed,
+                               void *stream);
+
+/* Replaces sparse_conv_ext.indice_conv_fp32 / indice_subm_conv (all.cc:21-51;
+ * indiceConv<float>, spconv_ops.h:260-361: gather -> mm -> scatter-add per offset) with one
+ * output-stationary kernel, fused with the layer's epilogue
+ *     y = conv(x) * scale + shift (+ residual) ; ReLU
+ * i.e. eval-mode BatchNorm1d folded (make_sparse_convmodule, mmdet3d/ops/sparse_block.py:
+ * 142-204) and the SparseBasicBlock tail (sparse_block.py:127-137).  scale/shift/residual may
+ * be NULL (plain convolution).  features_in is (n_in, cin_padded) f32; out (n_out, cout).
+ * k_first >= 0 accumulates that offset first (the reference adds the SubM centre first). */
+SF_API int sf_sparse_conv_f32(const float *features_in, int cin_padded, const int *nbr,
+                              int nbr_stride, int K, int k_first, const float *w_packed, int cout,
+                              const float *scale, const float *shift, const float *residual,
+                              int relu, float *out, const int *n_out_dev, int n_out_bound,
+                              void *stream);
+
+/* ------------------------------------------------------------------ dense BEV -------- */
+
+/* Replaces SparseConvTensor.dense() + view (mmdet3d/ops/spconv/structure.py:55-64,
+ * mmdet3d/models/middle_encoders/sparse_encoder.py:122-125): out (B, C*D, H, W) f32 with
+ * channel = c*D + z, zero where inactive (the zero fill is part of this call). */
+SF_API int sf_dense_bev(const float *features, const int *indices, const int *n_dev, int n_bound,
+                        int channels, int batch, int D, int H, int W, float *out, void *stream);
+
+/* Zero-pad feature columns: src (n, c_src) -> dst (n, c_dst), c_dst >= c_src. */
+SF_API int sf_pad_channels_f32(const float *src, int c_src, float *dst, int c_dst,
+                               const int *n_dev, int n_bound, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPARSEFUSION_HIP_H_ */

@@ -1,0 +1,343 @@
+"""numpy/ctypes front-end of the CPU ORACLE (test infrastructure, NOT product code).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this
+module.  It wraps oracle/liboracle.so (plain-C restatement of the reference's CPU
+algorithms, see sf_oracle.c) and restates the layer wiring of the reference's
+SparseEncoder (mmdet3d/models/middle_encoders/sparse_encoder.py:31-203,
+mmdet3d/ops/sparse_block.py:116-204, mmdet3d/ops/spconv/conv.py:113-204).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+_f32p = np.ctypeslib.ndpointer(np.float32, flags='C_CONTIGUOUS')
+_i32p = np.ctypeslib.ndpointer(np.int32, flags='C_CONTIGUOUS')
+
+
+def build():
+    """Compile liboracle.so (gcc).  Building the checker is not using it."""
+    subprocess.check_call(['make', '-s', '-C', _HERE, 'liboracle.so'])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, 'liboracle.so')
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.sfo_grid_size.argtypes = [_f32p, _f32p, _i32p]
+        L.sfo_dynamic_voxelize.argtypes = [_f32p, C.c_int, C.c_int, _f32p, _f32p, _i32p]
+        L.sfo_hard_voxelize.argtypes = [_f32p, C.c_int, C.c_int, _f32p, _f32p, C.c_int, C.c_int,
+                                        _f32p, _i32p, _i32p]
+        L.sfo_hard_voxelize.restype = C.c_int
+        L.sfo_vfe_mean.argtypes = [_f32p, _i32p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]
+        L.sfo_voxel_heights.argtypes = [_f32p, _i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, C.c_int, _f32p, _f32p]
+        L.sfo_indice_pairs_subm.argtypes = [_i32p, C.c_int, C.c_int, _i32p, _i32p, _i32p, _i32p,
+                                            _i32p]
+        L.sfo_indice_pairs_subm.restype = C.c_int
+        L.sfo_indice_pairs_conv.argtypes = [_i32p, C.c_int, C.c_int, _i32p, _i32p, _i32p, _i32p,
+                                            _i32p, _i32p, _i32p, _i32p]
+        L.sfo_indice_pairs_conv.restype = C.c_int
+        L.sfo_indice_conv.argtypes = [_f32p, C.c_int, C.c_int, _f32p, C.c_int, _i32p, _i32p,
+                                      C.c_int, C.c_int, C.c_int, C.c_int, _f32p]
+        L.sfo_indice_conv.restype = C.c_int
+        L.sfo_bn_act.argtypes = [_f32p, C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_float,
+                                 C.c_void_p, C.c_int]
+        L.sfo_dense_bev.argtypes = [_f32p, _i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, _f32p]
+        L.sfo_num_threads.restype = C.c_int
+        _LIB = L
+    return _LIB
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _triple(v):
+    if isinstance(v, (list, tuple)):
+        assert len(v) == 3
+        return [int(x) for x in v]
+    return [int(v)] * 3
+
+
+# ---------------------------------------------------------------- voxelize
+
+def grid_size(voxel_size, coors_range):
+    g = np.zeros(3, np.int32)
+    lib().sfo_grid_size(_f32(voxel_size), _f32(coors_range), g)
+    return g
+
+
+def dynamic_voxelize(points, voxel_size, coors_range):
+    """-> coors (N,3) int32 (z,y,x), -1 rows for rejected points."""
+    points = _f32(points)
+    coors = np.zeros((points.shape[0], 3), np.int32)
+    lib().sfo_dynamic_voxelize(points, points.shape[0], points.shape[1], _f32(voxel_size),
+                               _f32(coors_range), coors)
+    return coors
+
+
+def hard_voxelize(points, voxel_size, coors_range, max_points, max_voxels):
+    """-> (voxels (M,max_points,F), coors (M,3), num_points (M,)) as voxelize.py:46-58."""
+    points = _f32(points)
+    n, f = points.shape
+    voxels = np.zeros((max_voxels, max_points, f), np.float32)
+    coors = np.zeros((max_voxels, 3), np.int32)
+    npv = np.zeros((max_voxels,), np.int32)
+    m = lib().sfo_hard_voxelize(points, n, f, _f32(voxel_size), _f32(coors_range), max_points,
+                                max_voxels, voxels, coors, npv)
+    if m < 0:
+        raise MemoryError('oracle dense grid allocation failed')
+    return voxels[:m], coors[:m], npv[:m]
+
+
+def vfe_mean(voxels, num_points, num_features):
+    voxels = _f32(voxels)
+    m, mp, f = voxels.shape
+    out = np.zeros((m, num_features), np.float32)
+    if m:
+        lib().sfo_vfe_mean(voxels, _i32(num_points), m, mp, f, num_features, out)
+    return out
+
+
+def voxel_heights(voxels, coors4, batch, grid_xyz, out_size_factor):
+    voxels = _f32(voxels)
+    m, mp, f = voxels.shape
+    nx, ny = grid_xyz[0] // out_size_factor, grid_xyz[1] // out_size_factor
+    mn = np.zeros((batch, ny, nx), np.float32)
+    mx = np.zeros((batch, ny, nx), np.float32)
+    lib().sfo_voxel_heights(voxels, _i32(coors4), m, mp, f, batch, ny, nx, out_size_factor, mn, mx)
+    return mn, mx
+
+
+def batch_coors(coors_list):
+    """detectors/sparsefusion.py:153-157: prepend the sample index."""
+    out = []
+    for i, c in enumerate(coors_list):
+        out.append(np.concatenate([np.full((c.shape[0], 1), i, np.int32), c.astype(np.int32)], 1))
+    return np.concatenate(out, 0) if out else np.zeros((0, 4), np.int32)
+
+
+# ---------------------------------------------------------------- rulebook
+
+def conv_output_size(in_shape, ksize, stride, padding, dilation):
+    """ops/spconv/ops.py:20-30."""
+    return [(in_shape[i] + 2 * padding[i] - dilation[i] * (ksize[i] - 1) - 1) // stride[i] + 1
+            for i in range(3)]
+
+
+def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padding=0, dilation=1,
+                     subm=False):
+    """ops/spconv/ops.py:46-105 -> (outids (M,4), indice_pairs (K,2,N), indice_num (K,), out_shape).
+
+    CPU reference order: outputs in first-touch order, pairs in input order."""
+    indices = _i32(indices)
+    n = indices.shape[0]
+    ks, st, pd, dl = _triple(ksize), _triple(stride), _triple(padding), _triple(dilation)
+    K = ks[0] * ks[1] * ks[2]
+    pairs = np.full((K, 2, n), -1, np.int32)
+    num = np.zeros((K,), np.int32)
+    if subm:
+        out_shape = list(spatial_shape)
+        if n:
+            r = lib().sfo_indice_pairs_subm(indices, n, int(batch_size), _i32(out_shape), _i32(ks),
+                                            _i32(dl), pairs, num)
+            if r < 0:
+                raise MemoryError
+        return indices.copy(), pairs, num, out_shape
+    out_shape = conv_output_size(spatial_shape, ks, st, pd, dl)
+    outids = np.zeros((max(n * K, 1), 4), np.int32)
+    m = 0
+    if n:
+        m = lib().sfo_indice_pairs_conv(indices, n, int(batch_size), _i32(out_shape), _i32(ks),
+                                        _i32(st), _i32(pd), _i32(dl), outids, pairs, num)
+        if m < 0:
+            raise MemoryError
+    return outids[:m].copy(), pairs, num, out_shape
+
+
+def linear_index(indices, shape):
+    i = indices.astype(np.int64)
+    return ((i[:, 0] * shape[0] + i[:, 1]) * shape[1] + i[:, 2]) * shape[2] + i[:, 3]
+
+
+def canonical_rulebook(in_indices, in_shape, outids, out_shape, pairs, num):
+    """SURVEY 8a-R canonical form: outputs sorted by linear index; per offset the set of
+    (in_linear, out_linear) pairs sorted by in_linear.  Order-free, row-numbering-free."""
+    lin_in = linear_index(in_indices, in_shape)
+    lin_out = linear_index(outids, out_shape)
+    res = {'out_sorted': np.sort(lin_out), 'num': num.astype(np.int32).copy(), 'pairs': []}
+    for k in range(pairs.shape[0]):
+        c = int(num[k])
+        a = lin_in[pairs[k, 0, :c]]
+        b = lin_out[pairs[k, 1, :c]]
+        o = np.argsort(a, kind='stable')
+        res['pairs'].append(np.stack([a[o], b[o]], 0))
+    return res
+
+
+# ---------------------------------------------------------------- conv
+
+def indice_conv(features, filters_kio, pairs, num, n_out, subm):
+    """filters_kio: (K, Cin, Cout) fp32 (spconv-1.x layout flattened)."""
+    features = _f32(features)
+    w = _f32(filters_kio)
+    K, cin, cout = w.shape
+    out = np.zeros((n_out, cout), np.float32)
+    if n_out == 0:
+        return out
+    pairs = _i32(pairs)
+    r = lib().sfo_indice_conv(features, features.shape[0], cin, w, cout, pairs, _i32(num), K,
+                              pairs.shape[2], n_out, int(bool(subm)), out)
+    if r < 0:
+        raise MemoryError
+    return out
+
+
+def bn_act(x, bn, eps, residual=None, relu=True):
+    """bn = dict(weight, bias, running_mean, running_var) -> in-place on a copy."""
+    x = _f32(x).copy()
+    if x.shape[0] == 0:
+        return x
+    res = None
+    if residual is not None:
+        residual = _f32(residual)
+        res = residual.ctypes.data_as(C.c_void_p)
+    lib().sfo_bn_act(x, x.shape[0], x.shape[1], _f32(bn['weight']), _f32(bn['bias']),
+                     _f32(bn['running_mean']), _f32(bn['running_var']), float(eps), res,
+                     int(bool(relu)))
+    return x
+
+
+def dense_bev(features, indices, batch, shape):
+    features = _f32(features)
+    c = features.shape[1]
+    D, H, W = shape
+    out = np.zeros((batch, c * D, H, W), np.float32)
+    lib().sfo_dense_bev(features, _i32(indices), features.shape[0], c, batch, D, H, W, out)
+    return out
+
+
+def weight_to_kio(w, ksize, in_channels, out_channels):
+    """Accept spconv-2 layout (Cout,kD,kH,kW,Cin) [write_spconv2.py:46-47] or spconv-1 layout
+    (kD,kH,kW,Cin,Cout) [conv.py:98-99]; return (K,Cin,Cout).  When both layouts fit the shape
+    (all five extents equal) the spconv-2 reading wins: that is what the reference's
+    checkpoints hold."""
+    w = np.asarray(w, np.float32)
+    ks = tuple(_triple(ksize))
+    if w.shape == (out_channels,) + ks + (in_channels,):
+        w = np.transpose(w, (1, 2, 3, 4, 0))
+    else:
+        assert w.shape == ks + (in_channels, out_channels), w.shape
+    return np.ascontiguousarray(w.reshape(-1, in_channels, out_channels))
+
+
+# ---------------------------------------------------------------- SparseEncoder wiring
+
+def encoder_layer_specs(in_channels, base_channels=16, output_channels=128,
+                        encoder_channels=((16,), (32, 32, 32), (64, 64, 64), (64, 64, 64)),
+                        encoder_paddings=((1,), (1, 1, 1), (1, 1, 1), ((0, 1, 1), 1, 1)),
+                        block_type='conv_module'):
+    """Flat op list restating sparse_encoder.py:59-93 (post-activate order) and :129-203.
+
+    Each entry: dict(kind='convmodule'|'basicblock', prefix=<state-dict prefix>, cin, cout,
+    ksize, stride, padding, subm, indice_key)."""
+    specs = [dict(kind='convmodule', prefix='conv_input', cin=in_channels, cout=base_channels,
+                  ksize=3, stride=1, padding=1, subm=True, indice_key='subm1')]
+    cin = base_channels
+    for i, blocks in enumerate(encoder_channels):
+        for j, cout in enumerate(tuple(blocks)):
+            padding = tuple(encoder_paddings[i])[j]
+            prefix = f'encoder_layers.encoder_layer{i + 1}.{j}'
+            if i != 0 and j == 0 and block_type == 'conv_module':
+                specs.append(dict(kind='convmodule', prefix=prefix, cin=cin, cout=cout, ksize=3,
+                                  stride=2, padding=padding, subm=False,
+                                  indice_key=f'spconv{i + 1}'))
+            elif block_type == 'basicblock':
+                if j == len(blocks) - 1 and i != len(encoder_channels) - 1:
+                    specs.append(dict(kind='convmodule', prefix=prefix, cin=cin, cout=cout,
+                                      ksize=3, stride=2, padding=padding, subm=False,
+                                      indice_key=f'spconv{i + 1}'))
+                else:
+                    specs.append(dict(kind='basicblock', prefix=prefix, cin=cout, cout=cout,
+                                      ksize=3, stride=1, padding=1, subm=True, indice_key=None))
+            else:
+                specs.append(dict(kind='convmodule', prefix=prefix, cin=cin, cout=cout, ksize=3,
+                                  stride=1, padding=padding, subm=True,
+                                  indice_key=f'subm{i + 1}'))
+            cin = cout
+    specs.append(dict(kind='convmodule', prefix='conv_out', cin=cin, cout=output_channels,
+                      ksize=(3, 1, 1), stride=(2, 1, 1), padding=0, subm=False,
+                      indice_key='spconv_down2'))
+    return specs
+
+
+def _bn(sd, prefix):
+    return {k: np.asarray(sd[f'{prefix}.{k}'], np.float32)
+            for k in ('weight', 'bias', 'running_mean', 'running_var')}
+
+
+def sparse_encoder_forward(state_dict, voxel_features, coors, batch_size, sparse_shape,
+                           in_channels, bn_eps=1e-3, trace=None, **cfg):
+    """SparseEncoder.forward (sparse_encoder.py:95-127) on the CPU oracle.
+
+    state_dict: numpy arrays under the reference's key names.  `trace`, if a dict, receives
+    per-layer rulebooks / features for parity tests."""
+    specs = encoder_layer_specs(in_channels, **cfg)
+    feats = _f32(voxel_features)
+    idx = _i32(coors)
+    shape = list(sparse_shape)
+    cache = {}
+
+    def rulebook(spec, idx, shape):
+        key = spec['indice_key']
+        if key is not None and key in cache:
+            return cache[key]
+        rb = get_indice_pairs(idx, batch_size, shape, spec['ksize'], spec['stride'],
+                              spec['padding'], 1, spec['subm'])
+        if key is not None:
+            cache[key] = rb
+        return rb
+
+    for li, spec in enumerate(specs):
+        p = spec['prefix']
+        if spec['kind'] == 'convmodule':
+            outids, pairs, num, oshape = rulebook(spec, idx, shape)
+            w = weight_to_kio(state_dict[f'{p}.0.weight'], spec['ksize'], spec['cin'], spec['cout'])
+            y = indice_conv(feats, w, pairs, num, outids.shape[0], spec['subm'])
+            y = bn_act(y, _bn(state_dict, f'{p}.1'), bn_eps, None, True)
+            if trace is not None:
+                trace[p] = dict(in_indices=idx, in_shape=list(shape), outids=outids,
+                                out_shape=list(oshape), pairs=pairs, num=num, features=y)
+            feats, idx, shape = y, outids, list(oshape)
+        else:  # SparseBasicBlock.forward, sparse_block.py:116-139
+            identity = feats
+            outids, pairs, num, oshape = rulebook(spec, idx, shape)
+            w1 = weight_to_kio(state_dict[f'{p}.conv1.weight'], 3, spec['cin'], spec['cout'])
+            y = indice_conv(feats, w1, pairs, num, outids.shape[0], True)
+            y = bn_act(y, _bn(state_dict, f'{p}.bn1'), bn_eps, None, True)
+            outids2, pairs2, num2, _ = rulebook(spec, idx, shape)  # rebuilt: no indice_key
+            w2 = weight_to_kio(state_dict[f'{p}.conv2.weight'], 3, spec['cout'], spec['cout'])
+            y = indice_conv(y, w2, pairs2, num2, outids2.shape[0], True)
+            y = bn_act(y, _bn(state_dict, f'{p}.bn2'), bn_eps, identity, True)
+            if trace is not None:
+                trace[p] = dict(in_indices=idx, in_shape=list(shape), outids=outids,
+                                out_shape=list(oshape), pairs=pairs, num=num, features=y)
+            feats = y
+    bev = dense_bev(feats, idx, int(batch_size), shape)
+    if trace is not None:
+        trace['out_indices'] = idx
+        trace['out_shape'] = list(shape)
+    return bev

@@ -1,0 +1,115 @@
+"""ctypes binding of libsparsefusion_hip.so (the C ABI declared in include/sparsefusion_hip.h).
+
+There is no fallback: if the library is missing or a tensor is not on a HIP device the ops raise.
+PyTorch is used only for device memory and streams.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libsparsefusion_hip.so')
+_LIB = None
+
+SF_OK = 0
+
+_vp, _i, _sz, _ll = C.c_void_p, C.c_int, C.c_size_t, C.c_longlong
+_F3, _F6, _I3 = C.c_float * 3, C.c_float * 6, C.c_int * 3   # array instances decay to pointers
+_f3 = _f6 = C.POINTER(C.c_float)
+_i3 = C.POINTER(C.c_int)
+
+# name -> (restype, argtypes); kept in step with include/sparsefusion_hip.h (tests check it)
+SIGNATURES = {
+    'sf_version': (_i, []),
+    'sf_last_error': (C.c_char_p, []),
+    'sf_dynamic_voxelize': (_i, [_vp, _i, _i, _f3, _f6, _vp, _vp]),
+    'sf_hard_voxelize_workspace': (_sz, [_i, _i]),
+    'sf_hard_voxelize': (_i, [_vp, _i, _i, _f3, _f6, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i,
+                              _vp, _i, _vp, C.POINTER(_i), _vp, _sz, _vp]),
+    'sf_voxel_mean': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    'sf_hash_capacity': (_i, [_ll]),
+    'sf_hash_build': (_i, [_vp, _vp, _i, _i3, _i, _vp, _vp, _i, _vp, _vp]),
+    'sf_conv_output_set_workspace': (_sz, [_i, _i]),
+    'sf_conv_output_set': (_i, [_vp, _vp, _i, _i, _i3, _i3, _i3, _i3, _vp, _vp, _i, _vp, _i, _vp,
+                                _vp, _vp, _sz, _vp]),
+    'sf_neighbor_table': (_i, [_vp, _vp, _i, _i, _i3, _i3, _i3, _i3, _vp, _vp, _i, _i, _vp, _i,
+                               _vp]),
+    'sf_export_indice_pairs_workspace': (_sz, [_i, _i]),
+    'sf_export_indice_pairs': (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    'sf_indice_pairs_to_table': (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp]),
+    'sf_conv_padded_cin': (_i, [_i]),
+    'sf_pack_filters_f32': (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    'sf_sparse_conv_f32': (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp,
+                                _i, _vp]),
+    'sf_dense_bev': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    'sf_pad_channels_f32': (_i, [_vp, _i, _vp, _i, _vp, _i, _vp]),
+}
+
+
+def build(verbose=False):
+    """Compile the HIP library in-tree (hipcc --offload-arch=gfx950); works without a GPU."""
+    cmd = ['make', '-C', os.path.join(_HERE, 'csrc'), '-j8']
+    if not verbose:
+        cmd.insert(1, '-s')
+    subprocess.check_call(cmd)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; '
+                f'g.build()"` (there is no non-HIP fallback)')
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(rc):
+    if rc != SF_OK:
+        msg = lib().sf_last_error().decode('utf-8', 'replace')
+        raise RuntimeError(f'sparsefusion_hip error {rc}: {msg}')
+
+
+def f3(v):
+    return _F3(*[float(x) for x in v])
+
+
+def f6(v):
+    return _F6(*[float(x) for x in v])
+
+
+def i3(v):
+    if not isinstance(v, (list, tuple)):
+        v = [v, v, v]
+    assert len(v) == 3
+    return _I3(*[int(x) for x in v])
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Refuses host tensors: no CPU path exists."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError('sparsefusion_amd ops need tensors on a HIP device '
+                           f'(got {t.device}); there is no CPU path')
+    if not t.is_contiguous():
+        raise RuntimeError('sparsefusion_amd ops need contiguous tensors')
+    return t.data_ptr()
+
+
+def stream(device=None):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require(t, dtype, what):
+    if t.dtype != dtype:
+        raise RuntimeError(f'{what} must be {dtype}, got {t.dtype}')
+    return t

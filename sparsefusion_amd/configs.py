@@ -1,0 +1,48 @@
+"""Hot-path hyper-parameters of the two reference configs this build targets.
+
+nuScenes: configs/sparsefusion_nusc_voxel_LC_r50.py:1,6,153-170.
+Waymo:    configs/transfusion_waymo_voxel_L.py:1-3,109-134.
+The dict keys are the reference's own (`pts_voxel_layer`, `pts_voxel_encoder`,
+`pts_middle_encoder`), so a reference config can be passed through unchanged.
+"""
+
+NUSC = dict(
+    point_cloud_range=[-54.0, -54.0, -5.0, 54.0, 54.0, 3.0],
+    voxel_size=[0.075, 0.075, 0.2],
+    out_size_factor=8,
+    pts_voxel_layer=dict(
+        max_num_points=10,
+        voxel_size=[0.075, 0.075, 0.2],
+        max_voxels=(120000, 160000),
+        point_cloud_range=[-54.0, -54.0, -5.0, 54.0, 54.0, 3.0]),
+    pts_voxel_encoder=dict(type='HardSimpleVFE', num_features=5),
+    pts_middle_encoder=dict(
+        type='SparseEncoder',
+        in_channels=5,
+        sparse_shape=[41, 1440, 1440],
+        output_channels=128,
+        order=('conv', 'norm', 'act'),
+        encoder_channels=((16, 16, 32), (32, 32, 64), (64, 64, 128), (128, 128)),
+        encoder_paddings=((0, 0, 1), (0, 0, 1), (0, 0, [0, 1, 1]), (0, 0)),
+        block_type='basicblock'),
+)
+
+WAYMO = dict(
+    point_cloud_range=[-75.2, -75.2, -2, 75.2, 75.2, 4],
+    voxel_size=[0.1, 0.1, 0.15],
+    out_size_factor=8,
+    pts_voxel_layer=dict(
+        max_num_points=5,
+        voxel_size=[0.1, 0.1, 0.15],
+        max_voxels=150000,
+        point_cloud_range=[-75.2, -75.2, -2, 75.2, 75.2, 4]),
+    pts_middle_encoder=dict(
+        type='SparseEncoder',
+        in_channels=64,
+        sparse_shape=[41, 1504, 1504],
+        output_channels=128,
+        order=('conv', 'norm', 'act'),
+        encoder_channels=((16, 16, 32), (32, 32, 64), (64, 64, 128), (128, 128)),
+        encoder_paddings=((0, 0, 1), (0, 0, 1), (0, 0, [0, 1, 1]), (0, 0)),
+        block_type='basicblock'),
+)

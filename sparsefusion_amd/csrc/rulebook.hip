@@ -1,0 +1,475 @@
+// Rulebook construction for SubMConv3d / SparseConv3d on gfx950.
+//
+// The reference (spconv 1.x as vendored under mmdet3d/ops/spconv) keeps a dense int32 grid of
+// B*D*H*W cells per layer (spconv_ops.h:60-62, 340 MB at the first nuScenes stage) and emits
+// per-offset pair lists.  Here the active set lives in an open-addressing hash table sized to
+// the active count, and the rulebook is kept OUTPUT-major ("neighbour table"): for every output
+// row and kernel offset the input row or -1.  That is the form the output-stationary
+// convolution kernel consumes; sf_export_indice_pairs converts it to the reference's tensors.
+#include "sf_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kItems = 4;                  // inputs per thread in the output-set scan
+constexpr int kChunk = kThreads * kItems;
+
+struct Geo {
+  int ks[3], st[3], pad[3];
+  int oshape[3];  // output spatial shape (D,H,W)
+  int ishape[3];  // input spatial shape
+  int K;
+};
+
+__device__ __forceinline__ int load_n(const int *n_dev, int n_bound) {
+  int n = n_dev ? *n_dev : n_bound;
+  return n < n_bound ? n : n_bound;
+}
+
+__device__ __forceinline__ uint32_t lin_key(int b, int z, int y, int x, const int shape[3]) {
+  return (((uint32_t)b * (uint32_t)shape[0] + (uint32_t)z) * (uint32_t)shape[1] + (uint32_t)y) *
+             (uint32_t)shape[2] +
+         (uint32_t)x;
+}
+
+__global__ void table_fill_kernel(uint32_t *__restrict__ keys, int *__restrict__ vals, int cap,
+                                  int *__restrict__ extra, int n_extra, int extra_val) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+  for (int i = tid; i < cap; i += stride) {
+    keys[i] = SF_EMPTY_KEY;
+    vals[i] = SF_INT_MAX;
+  }
+  for (int i = tid; i < n_extra; i += stride) extra[i] = extra_val;
+}
+
+__global__ void hash_build_kernel(const int *__restrict__ indices, const int *n_dev, int n_bound,
+                                  Geo g, uint32_t *__restrict__ keys, int *__restrict__ vals,
+                                  uint32_t mask, int *overflow_dev) {
+  const int n = load_n(n_dev, n_bound);
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    int4 c = reinterpret_cast<const int4 *>(indices)[j];
+    int slot = sf_hash_insert(keys, mask, lin_key(c.x, c.y, c.z, c.w, g.ishape));
+    if (slot < 0) {
+      if (overflow_dev) *overflow_dev = 1;
+      continue;
+    }
+    atomicMin(&vals[slot], j);  // first occurrence wins for duplicate coordinates
+  }
+}
+
+// Enumerates the outputs reached from one input coordinate in the order of getValidOutPos
+// (geometry.h:57-83): ascending kernel-offset index; calls fn(k, oz, oy, ox).
+// An output o along a dim is reached through offset kd iff o*stride - pad + kd == in.
+template <typename F>
+__device__ __forceinline__ void for_each_output(const int4 c, const Geo &g, F fn) {
+  for (int k0 = 0; k0 < g.ks[0]; ++k0) {
+    int t0 = c.y + g.pad[0] - k0;
+    if (t0 < 0 || t0 % g.st[0]) continue;
+    int o0 = t0 / g.st[0];
+    if (o0 >= g.oshape[0]) continue;
+    for (int k1 = 0; k1 < g.ks[1]; ++k1) {
+      int t1 = c.z + g.pad[1] - k1;
+      if (t1 < 0 || t1 % g.st[1]) continue;
+      int o1 = t1 / g.st[1];
+      if (o1 >= g.oshape[1]) continue;
+      for (int k2 = 0; k2 < g.ks[2]; ++k2) {
+        int t2 = c.w + g.pad[2] - k2;
+        if (t2 < 0 || t2 % g.st[2]) continue;
+        int o2 = t2 / g.st[2];
+        if (o2 >= g.oshape[2]) continue;
+        fn((k0 * g.ks[1] + k1) * g.ks[2] + k2, o0, o1, o2);
+      }
+    }
+  }
+}
+
+// pass 1: insert every reachable output coordinate, remember its first toucher (input*K + k)
+__global__ void outset_insert_kernel(const int *__restrict__ indices, const int *n_dev,
+                                     int n_bound, Geo g, uint32_t *__restrict__ keys,
+                                     uint32_t mask, int *__restrict__ first, int *overflow_dev) {
+  const int n = load_n(n_dev, n_bound);
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    int4 c = reinterpret_cast<const int4 *>(indices)[j];
+    for_each_output(c, g, [&](int k, int oz, int oy, int ox) {
+      int slot = sf_hash_insert(keys, mask, lin_key(c.x, oz, oy, ox, g.oshape));
+      if (slot < 0) {
+        if (overflow_dev) *overflow_dev = 1;
+        return;
+      }
+      atomicMin(&first[slot], j * g.K + k);
+    });
+  }
+}
+
+// pass 2: per block, how many outputs are first touched by its inputs
+__global__ void __launch_bounds__(kThreads)
+outset_count_kernel(const int *__restrict__ indices, const int *n_dev, int n_bound, Geo g,
+                    const uint32_t *__restrict__ keys, uint32_t mask,
+                    const int *__restrict__ first, int *__restrict__ bsum) {
+  __shared__ int smem[17];
+  const int n = load_n(n_dev, n_bound);
+  int c = 0;
+  for (int e = 0; e < kItems; ++e) {
+    int j = blockIdx.x * kChunk + threadIdx.x * kItems + e;
+    if (j >= n) break;
+    int4 ci = reinterpret_cast<const int4 *>(indices)[j];
+    for_each_output(ci, g, [&](int k, int oz, int oy, int ox) {
+      int slot = sf_hash_find(keys, mask, lin_key(ci.x, oz, oy, ox, g.oshape));
+      if (slot >= 0 && first[slot] == j * g.K + k) ++c;
+    });
+  }
+  int total = sf_block_sum(c, smem);
+  if (threadIdx.x == 0) bsum[blockIdx.x] = total;
+}
+
+// pass 3: number the outputs in first-touch order, write outids and the row into the table
+__global__ void __launch_bounds__(kThreads)
+outset_assign_kernel(const int *__restrict__ indices, const int *n_dev, int n_bound, Geo g,
+                     const uint32_t *__restrict__ keys, uint32_t mask,
+                     const int *__restrict__ first, const int *__restrict__ bsum, int nblk,
+                     int *__restrict__ vals, int *__restrict__ outids, int outids_rows,
+                     int *__restrict__ n_out_dev, int *overflow_dev) {
+  __shared__ int smem[17];
+  const int n = load_n(n_dev, n_bound);
+  int before, all;
+  sf_block_prefix_of(bsum, nblk, blockIdx.x, smem, &before, &all);
+  int c = 0;
+  for (int e = 0; e < kItems; ++e) {
+    int j = blockIdx.x * kChunk + threadIdx.x * kItems + e;
+    if (j >= n) break;
+    int4 ci = reinterpret_cast<const int4 *>(indices)[j];
+    for_each_output(ci, g, [&](int k, int oz, int oy, int ox) {
+      int slot = sf_hash_find(keys, mask, lin_key(ci.x, oz, oy, ox, g.oshape));
+      if (slot >= 0 && first[slot] == j * g.K + k) ++c;
+    });
+  }
+  int total;
+  int row = before + sf_block_excl_scan(c, smem, &total);
+  for (int e = 0; e < kItems; ++e) {
+    int j = blockIdx.x * kChunk + threadIdx.x * kItems + e;
+    if (j >= n) break;
+    int4 ci = reinterpret_cast<const int4 *>(indices)[j];
+    for_each_output(ci, g, [&](int k, int oz, int oy, int ox) {
+      int slot = sf_hash_find(keys, mask, lin_key(ci.x, oz, oy, ox, g.oshape));
+      if (slot >= 0 && first[slot] == j * g.K + k) {
+        if (row < outids_rows) {
+          vals[slot] = row;
+          reinterpret_cast<int4 *>(outids)[row] = make_int4(ci.x, oz, oy, ox);
+        } else {
+          vals[slot] = -1;
+          if (overflow_dev) *overflow_dev = 1;
+        }
+        ++row;
+      }
+    });
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *n_out_dev = all < outids_rows ? all : outids_rows;
+}
+
+__global__ void neighbor_table_kernel(const int *__restrict__ outids, const int *n_out_dev,
+                                      int n_out_bound, Geo g, int batch,
+                                      const uint32_t *__restrict__ keys,
+                                      const int *__restrict__ vals, uint32_t mask,
+                                      int identity_center, int *__restrict__ nbr, int nbr_stride) {
+  const int n = load_n(n_out_dev, n_out_bound);
+  const long long total = (long long)n * g.K;
+  const int center = (g.K - 1) / 2;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    int k = (int)(e / n), o = (int)(e - (long long)k * n);
+    int res = -1;
+    if (identity_center && k == center) {
+      res = o;
+    } else {
+      int4 c = reinterpret_cast<const int4 *>(outids)[o];
+      int k2 = k % g.ks[2], k01 = k / g.ks[2];
+      int k1 = k01 % g.ks[1], k0 = k01 / g.ks[1];
+      int iz = c.y * g.st[0] - g.pad[0] + k0;
+      int iy = c.z * g.st[1] - g.pad[1] + k1;
+      int ix = c.w * g.st[2] - g.pad[2] + k2;
+      if (iz >= 0 && iz < g.ishape[0] && iy >= 0 && iy < g.ishape[1] && ix >= 0 &&
+          ix < g.ishape[2] && c.x >= 0 && c.x < batch) {
+        int slot = sf_hash_find(keys, mask, lin_key(c.x, iz, iy, ix, g.ishape));
+        if (slot >= 0) res = vals[slot];
+      }
+    }
+    nbr[(size_t)k * nbr_stride + o] = res;
+  }
+}
+
+// ---- export to the reference's (K,2,L) pair lists ------------------------------------
+__global__ void fill_int_kernel(int *__restrict__ p, long long n, int v) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    p[i] = v;
+}
+
+__global__ void export_invert_kernel(const int *__restrict__ nbr, int nbr_stride, int K,
+                                     const int *n_out_dev, int n_out_bound, int n_in,
+                                     int *__restrict__ inv) {
+  const int n = load_n(n_out_dev, n_out_bound);
+  const long long total = (long long)n * K;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    int k = (int)(e / n), o = (int)(e - (long long)k * n);
+    int in = nbr[(size_t)k * nbr_stride + o];
+    if (in >= 0 && in < n_in) inv[(size_t)k * n_in + in] = o;
+  }
+}
+
+__global__ void __launch_bounds__(kThreads)
+export_count_kernel(const int *__restrict__ inv, int n_in, int nblk, int *__restrict__ bsum) {
+  __shared__ int smem[17];
+  const int k = blockIdx.y;
+  int c = 0;
+  for (int e = 0; e < kItems; ++e) {
+    int i = blockIdx.x * kChunk + threadIdx.x * kItems + e;
+    if (i < n_in && inv[(size_t)k * n_in + i] >= 0) ++c;
+  }
+  int total = sf_block_sum(c, smem);
+  if (threadIdx.x == 0) bsum[k * nblk + blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(kThreads)
+export_write_kernel(const int *__restrict__ inv, int n_in, int nblk, const int *__restrict__ bsum,
+                    int *__restrict__ pairs, int *__restrict__ num) {
+  __shared__ int smem[17];
+  const int k = blockIdx.y;
+  int before, all;
+  sf_block_prefix_of(bsum + k * nblk, nblk, blockIdx.x, smem, &before, &all);
+  int c = 0;
+  int o[kItems];
+  for (int e = 0; e < kItems; ++e) {
+    int i = blockIdx.x * kChunk + threadIdx.x * kItems + e;
+    o[e] = (i < n_in) ? inv[(size_t)k * n_in + i] : -1;
+    if (o[e] >= 0) ++c;
+  }
+  int total;
+  int pos = before + sf_block_excl_scan(c, smem, &total);
+  for (int e = 0; e < kItems; ++e) {
+    if (o[e] < 0) continue;
+    int i = blockIdx.x * kChunk + threadIdx.x * kItems + e;
+    pairs[((size_t)k * 2 + 0) * n_in + pos] = i;
+    pairs[((size_t)k * 2 + 1) * n_in + pos] = o[e];
+    ++pos;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) num[k] = all;
+}
+
+__global__ void pairs_to_table_kernel(const int *__restrict__ pairs, const int *__restrict__ num,
+                                      int K, int L, int *__restrict__ nbr, int nbr_stride,
+                                      int n_out) {
+  const long long total = (long long)K * L;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    int k = (int)(e / L), i = (int)(e - (long long)k * L);
+    if (i >= num[k]) continue;
+    int in = pairs[((size_t)k * 2 + 0) * L + i], o = pairs[((size_t)k * 2 + 1) * L + i];
+    if (in >= 0 && o >= 0 && o < n_out) nbr[(size_t)k * nbr_stride + o] = in;
+  }
+}
+
+size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+int make_geo(const int ishape[3], const int oshape[3], const int ks[3], const int st[3],
+             const int pad[3], int batch, Geo *g) {
+  SF_CHECK_ARG(ks && st && pad, "ksize / stride / padding is NULL");
+  g->K = 1;
+  for (int i = 0; i < 3; ++i) {
+    SF_CHECK_ARG(ks[i] >= 1 && ks[i] <= 7 && st[i] >= 1 && pad[i] >= 0,
+                 "unsupported ksize/stride/padding at dim %d: %d/%d/%d", i, ks[i], st[i], pad[i]);
+    g->ks[i] = ks[i];
+    g->st[i] = st[i];
+    g->pad[i] = pad[i];
+    g->ishape[i] = ishape ? ishape[i] : 0;
+    g->oshape[i] = oshape ? oshape[i] : 0;
+    g->K *= ks[i];
+  }
+  const int *shapes[2] = {ishape, oshape};
+  for (int s = 0; s < 2; ++s) {
+    if (!shapes[s]) continue;
+    long long vol = batch;
+    for (int i = 0; i < 3; ++i) {
+      SF_CHECK_ARG(shapes[s][i] > 0, "spatial shape must be positive");
+      vol *= shapes[s][i];
+    }
+    if (vol >= 0xFFFFFFFFll) {
+      sf_set_error("batch*D*H*W = %lld does not fit 32-bit coordinate keys", vol);
+      return SF_ERR_CAPACITY;
+    }
+  }
+  return SF_OK;
+}
+
+bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+}  // namespace
+
+extern "C" int sf_hash_capacity(long long n_bound) {
+  long long want = 2 * (n_bound > 0 ? n_bound : 1);
+  long long cap = 1024;
+  while (cap < want && cap < (1ll << 30)) cap <<= 1;
+  return (int)cap;
+}
+
+extern "C" int sf_hash_build(const int *indices, const int *n_dev, int n_bound, const int shape[3],
+                             int batch, uint32_t *keys, int *vals, int capacity, int *overflow_dev,
+                             void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  SF_CHECK_ARG(n_bound >= 0 && batch >= 1 && shape, "bad n_bound/batch/shape");
+  SF_CHECK_ARG(keys && vals && is_pow2(capacity) && capacity >= n_bound,
+               "hash table NULL or capacity %d not a power of two >= n_bound %d", capacity,
+               n_bound);
+  SF_CHECK_ARG(n_bound == 0 || indices, "indices is NULL");
+  Geo g;
+  const int one[3] = {1, 1, 1}, zero[3] = {0, 0, 0};
+  int rc = make_geo(shape, nullptr, one, one, zero, batch, &g);
+  if (rc != SF_OK) return rc;
+  hipLaunchKernelGGL(table_fill_kernel, dim3(sf_grid(capacity, kThreads)), dim3(kThreads), 0, st,
+                     keys, vals, capacity, (int *)nullptr, 0, 0);
+  SF_CHECK_LAUNCH();
+  if (n_bound > 0) {
+    hipLaunchKernelGGL(hash_build_kernel, dim3(sf_grid(n_bound, kThreads)), dim3(kThreads), 0, st,
+                       indices, n_dev, n_bound, g, keys, vals, (uint32_t)(capacity - 1),
+                       overflow_dev);
+    SF_CHECK_LAUNCH();
+  }
+  return SF_OK;
+}
+
+extern "C" size_t sf_conv_output_set_workspace(int n_bound, int out_capacity) {
+  if (n_bound < 0 || out_capacity < 0) return 0;
+  int nblk = sf_div_up(n_bound > 0 ? n_bound : 1, kChunk);
+  return align_up((size_t)out_capacity * 4) + align_up((size_t)nblk * 4);
+}
+
+extern "C" int sf_conv_output_set(const int *indices, const int *n_dev, int n_bound, int batch,
+                                  const int out_shape[3], const int ksize[3], const int stride[3],
+                                  const int padding[3], uint32_t *out_keys, int *out_vals,
+                                  int out_capacity, int *outids, int outids_rows, int *n_out_dev,
+                                  int *overflow_dev, void *workspace, size_t workspace_bytes,
+                                  void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  SF_CHECK_ARG(n_bound >= 0 && batch >= 1 && out_shape, "bad n_bound/batch/out_shape");
+  SF_CHECK_ARG(out_keys && out_vals && is_pow2(out_capacity), "output table NULL or capacity %d "
+               "not a power of two", out_capacity);
+  SF_CHECK_ARG(outids && outids_rows >= 0 && n_out_dev, "outids / n_out_dev is NULL");
+  SF_CHECK_ARG(n_bound == 0 || indices, "indices is NULL");
+  Geo g;
+  int rc = make_geo(nullptr, out_shape, ksize, stride, padding, batch, &g);
+  if (rc != SF_OK) return rc;
+  SF_CHECK_ARG((long long)n_bound * g.K < 0x7FFFFFFFll, "n_bound*K overflows int32");
+  size_t need = sf_conv_output_set_workspace(n_bound, out_capacity);
+  if (!workspace || workspace_bytes < need) {
+    sf_set_error("workspace too small: %zu < %zu bytes", workspace_bytes, need);
+    return SF_ERR_WORKSPACE;
+  }
+  int *first = (int *)workspace;
+  int *bsum = (int *)((char *)workspace + align_up((size_t)out_capacity * 4));
+  const int nblk = sf_div_up(n_bound > 0 ? n_bound : 1, kChunk);
+  const uint32_t mask = (uint32_t)(out_capacity - 1);
+  hipLaunchKernelGGL(table_fill_kernel, dim3(sf_grid(out_capacity, kThreads)), dim3(kThreads), 0,
+                     st, out_keys, first, out_capacity, out_vals, out_capacity, -1);
+  SF_CHECK_LAUNCH();
+  hipLaunchKernelGGL(outset_insert_kernel, dim3(sf_grid(n_bound, kThreads)), dim3(kThreads), 0, st,
+                     indices, n_dev, n_bound, g, out_keys, mask, first, overflow_dev);
+  SF_CHECK_LAUNCH();
+  hipLaunchKernelGGL(outset_count_kernel, dim3(nblk), dim3(kThreads), 0, st, indices, n_dev,
+                     n_bound, g, (const uint32_t *)out_keys, mask, (const int *)first, bsum);
+  SF_CHECK_LAUNCH();
+  hipLaunchKernelGGL(outset_assign_kernel, dim3(nblk), dim3(kThreads), 0, st, indices, n_dev,
+                     n_bound, g, (const uint32_t *)out_keys, mask, (const int *)first,
+                     (const int *)bsum, nblk, out_vals, outids, outids_rows, n_out_dev,
+                     overflow_dev);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+extern "C" int sf_neighbor_table(const int *outids, const int *n_out_dev, int n_out_bound,
+                                 int batch, const int in_shape[3], const int ksize[3],
+                                 const int stride[3], const int padding[3],
+                                 const uint32_t *in_keys, const int *in_vals, int in_capacity,
+                                 int identity_center, int *nbr, int nbr_stride, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  SF_CHECK_ARG(n_out_bound >= 0 && batch >= 1 && in_shape, "bad n_out_bound/batch/in_shape");
+  SF_CHECK_ARG(in_keys && in_vals && is_pow2(in_capacity), "input table NULL or capacity %d not "
+               "a power of two", in_capacity);
+  SF_CHECK_ARG(nbr && nbr_stride >= n_out_bound, "nbr NULL or nbr_stride %d < n_out_bound %d",
+               nbr_stride, n_out_bound);
+  Geo g;
+  int rc = make_geo(in_shape, nullptr, ksize, stride, padding, batch, &g);
+  if (rc != SF_OK) return rc;
+  SF_CHECK_ARG(!identity_center || (g.K % 2 == 1), "identity_center needs an odd kernel volume");
+  if (n_out_bound == 0) return SF_OK;
+  SF_CHECK_ARG(outids, "outids is NULL");
+  hipLaunchKernelGGL(neighbor_table_kernel, dim3(sf_grid((long long)n_out_bound * g.K, kThreads)),
+                     dim3(kThreads), 0, st, outids, n_out_dev, n_out_bound, g, batch, in_keys,
+                     in_vals, (uint32_t)(in_capacity - 1), identity_center, nbr, nbr_stride);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+extern "C" size_t sf_export_indice_pairs_workspace(int K, int n_in) {
+  if (K < 1 || n_in < 0) return 0;
+  int nblk = sf_div_up(n_in > 0 ? n_in : 1, kChunk);
+  return align_up((size_t)K * (size_t)(n_in > 0 ? n_in : 1) * 4) + align_up((size_t)K * nblk * 4);
+}
+
+extern "C" int sf_export_indice_pairs(const int *nbr, int nbr_stride, int K, const int *n_out_dev,
+                                      int n_out_bound, int n_in, int *indice_pairs,
+                                      int *indice_num, void *workspace, size_t workspace_bytes,
+                                      void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  SF_CHECK_ARG(K >= 1 && n_in >= 0 && n_out_bound >= 0 && nbr_stride >= n_out_bound,
+               "bad K/n_in/n_out_bound/nbr_stride");
+  SF_CHECK_ARG(indice_num, "indice_num is NULL");
+  size_t need = sf_export_indice_pairs_workspace(K, n_in);
+  if (!workspace || workspace_bytes < need) {
+    sf_set_error("workspace too small: %zu < %zu bytes", workspace_bytes, need);
+    return SF_ERR_WORKSPACE;
+  }
+  SF_CHECK_HIP(hipMemsetAsync(indice_num, 0, sizeof(int) * K, st));
+  if (n_in == 0) return SF_OK;
+  SF_CHECK_ARG(nbr && indice_pairs, "nbr / indice_pairs is NULL");
+  int *inv = (int *)workspace;
+  int *bsum = (int *)((char *)workspace + align_up((size_t)K * n_in * 4));
+  const int nblk = sf_div_up(n_in, kChunk);
+  const long long cells = (long long)K * n_in;
+  hipLaunchKernelGGL(fill_int_kernel, dim3(sf_grid(cells, kThreads)), dim3(kThreads), 0, st, inv,
+                     cells, -1);
+  SF_CHECK_LAUNCH();
+  hipLaunchKernelGGL(fill_int_kernel, dim3(sf_grid(2 * cells, kThreads)), dim3(kThreads), 0, st,
+                     indice_pairs, 2 * cells, -1);
+  SF_CHECK_LAUNCH();
+  if (n_out_bound > 0) {
+    hipLaunchKernelGGL(export_invert_kernel, dim3(sf_grid((long long)n_out_bound * K, kThreads)),
+                       dim3(kThreads), 0, st, nbr, nbr_stride, K, n_out_dev, n_out_bound, n_in,
+                       inv);
+    SF_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(export_count_kernel, dim3(nblk, K), dim3(kThreads), 0, st, (const int *)inv,
+                     n_in, nblk, bsum);
+  SF_CHECK_LAUNCH();
+  hipLaunchKernelGGL(export_write_kernel, dim3(nblk, K), dim3(kThreads), 0, st, (const int *)inv,
+                     n_in, nblk, (const int *)bsum, indice_pairs, indice_num);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+extern "C" int sf_indice_pairs_to_table(const int *indice_pairs, const int *indice_num, int K,
+                                        int L, int n_out, int *nbr, int nbr_stride, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  SF_CHECK_ARG(K >= 1 && L >= 0 && n_out >= 0 && nbr_stride >= n_out, "bad K/L/n_out/nbr_stride");
+  if (n_out == 0) return SF_OK;
+  SF_CHECK_ARG(nbr && indice_num, "nbr / indice_num is NULL");
+  const long long cells = (long long)K * nbr_stride;
+  hipLaunchKernelGGL(fill_int_kernel, dim3(sf_grid(cells, kThreads)), dim3(kThreads), 0, st, nbr,
+                     cells, -1);
+  SF_CHECK_LAUNCH();
+  if (L == 0) return SF_OK;
+  SF_CHECK_ARG(indice_pairs, "indice_pairs is NULL");
+  hipLaunchKernelGGL(pairs_to_table_kernel, dim3(sf_grid((long long)K * L, kThreads)),
+                     dim3(kThreads), 0, st, indice_pairs, indice_num, K, L, nbr, nbr_stride, n_out);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}

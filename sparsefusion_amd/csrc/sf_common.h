@@ -1,0 +1,128 @@
+// Shared device/host helpers for the sparsefusion HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/sparsefusion_hip.h"
+
+#define SF_EMPTY_KEY 0xFFFFFFFFu
+#define SF_INT_MAX 0x7FFFFFFF
+#define SF_WAVE 64
+
+void sf_set_error(const char *fmt, ...);
+
+#define SF_CHECK_ARG(cond, ...)          \
+  do {                                   \
+    if (!(cond)) {                       \
+      sf_set_error(__VA_ARGS__);         \
+      return SF_ERR_BAD_ARG;             \
+    }                                    \
+  } while (0)
+
+#define SF_CHECK_HIP(expr)                                                        \
+  do {                                                                            \
+    hipError_t e_ = (expr);                                                       \
+    if (e_ != hipSuccess) {                                                       \
+      sf_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return SF_ERR_HIP;                                                          \
+    }                                                                             \
+  } while (0)
+
+#define SF_CHECK_LAUNCH() SF_CHECK_HIP(hipGetLastError())
+
+static inline int sf_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Grid for a grid-stride kernel over `items` with `threads` per block: enough blocks to fill
+// 256 CUs x 8 blocks, never more than the work needs, never zero.
+static inline int sf_grid(long long items, int threads) {
+  long long b = (items + threads - 1) / threads;
+  if (b < 1) b = 1;
+  if (b > 2048) b = 2048;
+  return (int)b;
+}
+
+// ---------------------------------------------------------------- device side
+__device__ __forceinline__ uint32_t sf_hash32(uint32_t k) {
+  // multiplicative (Fibonacci) hash followed by a xor-fold; capacity is a power of two
+  k *= 0x9E3779B1u;
+  return k ^ (k >> 15);
+}
+
+// Insert `key` into an open-addressing table of `mask+1` slots; returns the slot that holds
+// the key, or -1 if the table is full (caller raises the overflow flag).
+__device__ __forceinline__ int sf_hash_insert(uint32_t *keys, uint32_t mask, uint32_t key) {
+  uint32_t slot = sf_hash32(key) & mask;
+  for (uint32_t probe = 0; probe <= mask; ++probe) {
+    uint32_t cur = keys[slot];
+    if (cur == key) return (int)slot;
+    if (cur == SF_EMPTY_KEY) {
+      uint32_t prev = atomicCAS(&keys[slot], SF_EMPTY_KEY, key);
+      if (prev == SF_EMPTY_KEY || prev == key) return (int)slot;
+    }
+    slot = (slot + 1) & mask;
+  }
+  return -1;
+}
+
+// Look `key` up; returns the slot or -1.  The table is read-only while lookups run.
+__device__ __forceinline__ int sf_hash_find(const uint32_t *__restrict__ keys, uint32_t mask,
+                                            uint32_t key) {
+  uint32_t slot = sf_hash32(key) & mask;
+  for (uint32_t probe = 0; probe <= mask; ++probe) {
+    uint32_t cur = keys[slot];
+    if (cur == key) return (int)slot;
+    if (cur == SF_EMPTY_KEY) return -1;
+    slot = (slot + 1) & mask;
+  }
+  return -1;
+}
+
+__device__ __forceinline__ int sf_wave_incl_scan(int v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    int o = __shfl_up(v, d, 64);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+
+// Exclusive scan of one int per thread over a block of up to 1024 threads (multiple of 64).
+// `smem` needs 17 ints.  Returns the exclusive prefix; *total receives the block sum.
+__device__ __forceinline__ int sf_block_excl_scan(int v, int *smem, int *total) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  int incl = sf_wave_incl_scan(v);
+  __syncthreads();  // smem may still be read from a previous call
+  if (lane == 63) smem[wid] = incl;
+  __syncthreads();
+  if (wid == 0) {
+    int w = (lane < nw) ? smem[lane] : 0;
+    int wi = sf_wave_incl_scan(w);
+    if (lane < nw) smem[lane] = wi - w;
+    if (lane == nw - 1) smem[16] = wi;
+  }
+  __syncthreads();
+  *total = smem[16];
+  return incl - v + smem[wid];
+}
+
+__device__ __forceinline__ int sf_block_sum(int v, int *smem) {
+  int t;
+  (void)sf_block_excl_scan(v, smem, &t);
+  return t;
+}
+
+// Sum of bsum[0..b) and of bsum[0..nb) computed cooperatively by the block (nb is small:
+// a few hundred).  smem needs 17 ints.
+__device__ __forceinline__ void sf_block_prefix_of(const int *__restrict__ bsum, int nb, int b,
+                                                   int *smem, int *before, int *all) {
+  int pb = 0, pa = 0;
+  for (int i = threadIdx.x; i < nb; i += blockDim.x) {
+    int v = bsum[i];
+    pa += v;
+    if (i < b) pb += v;
+  }
+  *before = sf_block_sum(pb, smem);
+  *all = sf_block_sum(pa, smem);
+}

@@ -1,0 +1,412 @@
+// Hard / dynamic voxelization for gfx950.
+//
+// Reference semantics (mmdet3d/ops/voxel/src/voxelization_cpu.cpp:43-99, the CUDA path
+// voxelization_cuda.cu:184-326 computes the same result with an O(N^2) search and a serial
+// <<<1,1>>> kernel): voxels are numbered in first-point order, the scan stops at the first point
+// that would open voxel number max_voxels, and each voxel keeps its first max_points points.
+//
+// MI355X formulation (all integer / byte work, HBM- and atomic-bound, no serial step):
+//   fill    : hash keys <- EMPTY, per-slot point lists <- INT_MAX
+//   insert  : per point: coordinate -> hash slot (atomicCAS); then a bounded sorted insert of
+//             the point index into the slot's list of the max_points SMALLEST indices
+//             (a cascade of atomicMin: slot s keeps the min of everything offered to it and
+//             passes the rest on; the multiset is conserved, so the result is order independent)
+//   count   : flag "point i is the first point of its voxel" (list head == i), block sums
+//   assign  : exclusive scan of the flags = voxel id in first-point order; the point whose
+//             voxel id equals max_voxels is the cut (reference `break`); writes coors
+//   write   : voxels[v][s][:] = points[list[s]] for list entries below the cut, zeros elsewhere
+//   reduce  : num_points_per_voxel and the fused HardSimpleVFE mean
+#include "sf_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kItems = 8;                    // points per thread in the scan kernels
+constexpr int kChunk = kThreads * kItems;    // points per block in the scan kernels
+
+struct VoxParams {
+  float vs[3];
+  float lo[3];
+  int grid[3];  // x, y, z
+};
+
+// voxelization_cpu.cpp:20-37 / voxelization_cuda.cu:33-55.  IEEE subtract, IEEE divide, floor.
+// The comparison is done on the float so NaN / Inf / huge values are rejected explicitly (the
+// reference reaches the same outcome through an out-of-range float->int cast).
+__device__ __forceinline__ bool point_coor(const float *__restrict__ p, const VoxParams &vp,
+                                           int c_zyx[3]) {
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    float v = floorf((p[j] - vp.lo[j]) / vp.vs[j]);
+    if (!(v >= 0.0f && v < (float)vp.grid[j])) return false;
+    c_zyx[2 - j] = (int)v;
+  }
+  return true;
+}
+
+__global__ void dynamic_voxelize_kernel(const float *__restrict__ points, int n, int f,
+                                        VoxParams vp, int *__restrict__ coors) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    int c[3];
+    bool ok = point_coor(points + (size_t)i * f, vp, c);
+    coors[3 * (size_t)i + 0] = ok ? c[0] : -1;
+    coors[3 * (size_t)i + 1] = ok ? c[1] : -1;
+    coors[3 * (size_t)i + 2] = ok ? c[2] : -1;
+  }
+}
+
+// misc words: [0] cut point index, [1] voxel_num of this call, [2] overflow, [3] base row
+__global__ void vox_fill_kernel(uint32_t *__restrict__ keys, long long n_keys,
+                                int *__restrict__ lists, long long n_lists,
+                                int *__restrict__ misc, const int *__restrict__ row_count_dev) {
+  long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = tid; i < n_keys; i += stride) keys[i] = SF_EMPTY_KEY;
+  for (long long i = tid; i < n_lists; i += stride) lists[i] = SF_INT_MAX;
+  if (tid == 0) {
+    misc[0] = SF_INT_MAX;
+    misc[1] = 0;
+    misc[2] = 0;
+    misc[3] = row_count_dev ? *row_count_dev : 0;
+  }
+}
+
+__global__ void vox_insert_kernel(const float *__restrict__ points, int n, int f, VoxParams vp,
+                                  int max_points, uint32_t *__restrict__ keys, uint32_t mask,
+                                  int *__restrict__ lists, int *__restrict__ pslot,
+                                  int *__restrict__ misc) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    int c[3];
+    if (!point_coor(points + (size_t)i * f, vp, c)) {
+      pslot[i] = -1;
+      continue;
+    }
+    uint32_t key = ((uint32_t)c[0] * (uint32_t)vp.grid[1] + (uint32_t)c[1]) * (uint32_t)vp.grid[0] +
+                   (uint32_t)c[2];
+    int slot = sf_hash_insert(keys, mask, key);
+    pslot[i] = slot;
+    if (slot < 0) {  // cannot happen with capacity >= n; kept as a guard
+      misc[2] = 1;
+      continue;
+    }
+    int *list = lists + (size_t)slot * max_points;
+    int v = i;
+    for (int s = 0; s < max_points; ++s) {
+      // entries only ever decrease, so a (possibly stale) smaller value means "not ours"
+      int cur = __builtin_nontemporal_load(list + s);
+      if (cur < v) continue;
+      int old = atomicMin(list + s, v);
+      if (old > v) v = old;  // we took the slot, carry the displaced value on
+      if (v == SF_INT_MAX) break;
+    }
+  }
+}
+
+__device__ __forceinline__ bool is_first_point(int i, int n, const int *__restrict__ pslot,
+                                               const int *__restrict__ lists, int max_points,
+                                               int *slot_out) {
+  if (i >= n) return false;
+  int slot = pslot[i];
+  *slot_out = slot;
+  if (slot < 0) return false;
+  return lists[(size_t)slot * max_points] == i;
+}
+
+__global__ void __launch_bounds__(kThreads)
+vox_count_kernel(int n, int max_points, const int *__restrict__ pslot,
+                 const int *__restrict__ lists, int *__restrict__ bsum) {
+  __shared__ int smem[17];
+  int base = blockIdx.x * kChunk + threadIdx.x * kItems;
+  int c = 0;
+#pragma unroll
+  for (int e = 0; e < kItems; ++e) {
+    int slot;
+    c += is_first_point(base + e, n, pslot, lists, max_points, &slot) ? 1 : 0;
+  }
+  int total = sf_block_sum(c, smem);
+  if (threadIdx.x == 0) bsum[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(kThreads)
+vox_assign_kernel(int n, int max_points, int max_voxels, VoxParams vp, const int *__restrict__ pslot,
+                  const int *__restrict__ lists, const uint32_t *__restrict__ keys,
+                  const int *__restrict__ bsum, int nblk, int *__restrict__ vox_slot,
+                  int *__restrict__ coors, int coors_stride, int batch_idx, int rows_capacity,
+                  int *__restrict__ misc, int *__restrict__ row_count_dev,
+                  int *__restrict__ overflow_dev) {
+  __shared__ int smem[17];
+  int before, all;
+  sf_block_prefix_of(bsum, nblk, blockIdx.x, smem, &before, &all);
+  const int base_row = misc[3];
+  int base = blockIdx.x * kChunk + threadIdx.x * kItems;
+  int slots[kItems];
+  unsigned flags = 0;
+  int c = 0;
+#pragma unroll
+  for (int e = 0; e < kItems; ++e) {
+    int slot = -1;
+    bool f = is_first_point(base + e, n, pslot, lists, max_points, &slot);
+    slots[e] = slot;
+    flags |= (f ? 1u : 0u) << e;
+    c += f ? 1 : 0;
+  }
+  int total;
+  int vid = before + sf_block_excl_scan(c, smem, &total);
+#pragma unroll
+  for (int e = 0; e < kItems; ++e) {
+    if (!((flags >> e) & 1u)) continue;
+    if (max_voxels >= 0 && vid == max_voxels) misc[0] = base + e;  // the reference's `break`
+    if (max_voxels < 0 || vid < max_voxels) {
+      vox_slot[vid] = slots[e];
+      int row = base_row + vid;
+      if (row < rows_capacity) {
+        uint32_t key = keys[slots[e]];
+        uint32_t gx = (uint32_t)vp.grid[0], gy = (uint32_t)vp.grid[1];
+        int x = (int)(key % gx);
+        uint32_t zy = key / gx;
+        int y = (int)(zy % gy), z = (int)(zy / gy);
+        int *o = coors + (size_t)row * coors_stride;
+        if (coors_stride == 4) *o++ = batch_idx;
+        o[0] = z;
+        o[1] = y;
+        o[2] = x;
+      } else if (overflow_dev) {
+        *overflow_dev = 1;
+      }
+    }
+    ++vid;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    int vnum = (max_voxels >= 0 && all > max_voxels) ? max_voxels : all;
+    if (base_row + vnum > rows_capacity) {
+      vnum = rows_capacity > base_row ? rows_capacity - base_row : 0;
+      if (overflow_dev) *overflow_dev = 1;
+    }
+    misc[1] = vnum;
+    if (row_count_dev) *row_count_dev = base_row + vnum;
+  }
+}
+
+__global__ void vox_write_kernel(const float *__restrict__ points, int f, int max_points,
+                                 const int *__restrict__ lists, const int *__restrict__ vox_slot,
+                                 const int *__restrict__ misc, float *__restrict__ voxels) {
+  const int vnum = misc[1], cut = misc[0], base_row = misc[3];
+  const long long total = (long long)vnum * max_points * f;
+  const int per_voxel = max_points * f;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    int vid = (int)(e / per_voxel);
+    int r = (int)(e - (long long)vid * per_voxel);
+    int s = r / f, k = r - s * f;
+    int j = lists[(size_t)vox_slot[vid] * max_points + s];
+    float v = (j < cut) ? points[(size_t)j * f + k] : 0.0f;
+    voxels[(size_t)(base_row + vid) * per_voxel + r] = v;
+  }
+}
+
+// num_points_per_voxel (voxelization_cpu.cpp:89-95) + HardSimpleVFE mean (voxel_encoder.py:42-44:
+// sum over the slots in order, zeros included, divided by the count).
+__global__ void vox_reduce_kernel(const float *__restrict__ points, int f, int max_points,
+                                  const int *__restrict__ lists, const int *__restrict__ vox_slot,
+                                  const int *__restrict__ misc, int *__restrict__ npv,
+                                  float *__restrict__ mean, int mean_features, int mean_stride) {
+  const int vnum = misc[1], cut = misc[0], base_row = misc[3];
+  const int cols = mean ? mean_stride : 1;
+  const long long total = (long long)vnum * cols;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    int vid = (int)(e / cols), k = (int)(e - (long long)vid * cols);
+    const int *list = lists + (size_t)vox_slot[vid] * max_points;
+    int cnt = 0;
+    float sum = 0.0f;
+    const bool want = mean && k < mean_features;
+    for (int s = 0; s < max_points; ++s) {
+      int j = list[s];
+      if (j >= cut) break;  // lists ascend; INT_MAX marks empty
+      ++cnt;
+      if (want) sum += points[(size_t)j * f + k];
+    }
+    if (k == 0 && npv) npv[base_row + vid] = cnt;
+    if (mean) mean[(size_t)(base_row + vid) * mean_stride + k] = want ? sum / (float)cnt : 0.0f;
+  }
+}
+
+// Standalone HardSimpleVFE (voxel_encoder.py:42-44) on an already materialised voxel tensor.
+__global__ void voxel_mean_kernel(const float *__restrict__ voxels, const int *__restrict__ npv,
+                                  const int *m_dev, int m_bound, int max_points, int f, int nf,
+                                  float *__restrict__ out, int out_stride) {
+  int m = m_dev ? *m_dev : m_bound;
+  if (m > m_bound) m = m_bound;
+  const long long total = (long long)m * out_stride;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    int v = (int)(e / out_stride), k = (int)(e - (long long)v * out_stride);
+    float r = 0.0f;
+    if (k < nf) {
+      float sum = 0.0f;
+      const float *base = voxels + (size_t)v * max_points * f + k;
+      for (int s = 0; s < max_points; ++s) sum += base[(size_t)s * f];
+      r = sum / (float)npv[v];
+    }
+    out[e] = r;
+  }
+}
+
+size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct VoxWorkspace {
+  uint32_t *keys;
+  int *lists, *pslot, *bsum, *misc, *vox_slot;
+  long long cap;
+  int nblk;
+  size_t bytes;
+};
+
+VoxWorkspace carve(void *ws, int n, int max_points) {
+  VoxWorkspace w;
+  long long want = (long long)n + n / 2;
+  if (want < 1024) want = 1024;
+  long long cap = 1024;
+  while (cap < want) cap <<= 1;
+  w.cap = cap;
+  w.nblk = sf_div_up(n > 0 ? n : 1, kChunk);
+  size_t off = 0;
+  char *b = (char *)ws;
+  w.keys = (uint32_t *)(b + off);
+  off += align_up((size_t)cap * 4);
+  w.lists = (int *)(b + off);
+  off += align_up((size_t)cap * (size_t)max_points * 4);
+  w.pslot = (int *)(b + off);
+  off += align_up((size_t)(n > 0 ? n : 1) * 4);
+  w.bsum = (int *)(b + off);
+  off += align_up((size_t)w.nblk * 4);
+  w.misc = (int *)(b + off);
+  off += align_up(64);
+  w.vox_slot = (int *)(b + off);
+  off += align_up((size_t)(n > 0 ? n : 1) * 4);
+  w.bytes = off;
+  return w;
+}
+
+int make_params(const float vs[3], const float range[6], VoxParams *vp) {
+  SF_CHECK_ARG(vs && range, "voxel_size / coors_range is NULL");
+  long long vol = 1;
+  for (int i = 0; i < 3; ++i) {
+    SF_CHECK_ARG(vs[i] > 0.0f, "voxel_size[%d] must be positive", i);
+    vp->vs[i] = vs[i];
+    vp->lo[i] = range[i];
+    float q = (range[3 + i] - range[i]) / vs[i];  // fp32, voxelization_cpu.cpp:119-122
+    vp->grid[i] = (int)roundf(q);
+    SF_CHECK_ARG(vp->grid[i] > 0, "empty grid along axis %d", i);
+    vol *= vp->grid[i];
+  }
+  if (vol >= 0xFFFFFFFFll) {
+    sf_set_error("voxel grid volume %lld does not fit 32-bit keys", vol);
+    return SF_ERR_CAPACITY;
+  }
+  return SF_OK;
+}
+
+}  // namespace
+
+extern "C" int sf_dynamic_voxelize(const float *points, int n, int f, const float voxel_size[3],
+                                   const float coors_range[6], int *coors, void *stream) {
+  SF_CHECK_ARG(n >= 0 && f >= 3, "bad shape n=%d f=%d (need f >= 3)", n, f);
+  VoxParams vp;
+  int rc = make_params(voxel_size, coors_range, &vp);
+  if (rc != SF_OK) return rc;
+  if (n == 0) return SF_OK;
+  SF_CHECK_ARG(points && coors, "points / coors is NULL");
+  hipLaunchKernelGGL(dynamic_voxelize_kernel, dim3(sf_grid(n, kThreads)), dim3(kThreads), 0,
+                     (hipStream_t)stream, points, n, f, vp, coors);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+extern "C" size_t sf_hard_voxelize_workspace(int n, int max_points) {
+  if (n < 0 || max_points < 1) return 0;
+  return carve(nullptr, n, max_points).bytes;
+}
+
+extern "C" int sf_hard_voxelize(const float *points, int n, int f, const float voxel_size[3],
+                                const float coors_range[6], int max_points, int max_voxels,
+                                float *voxels, int *coors, int coors_stride, int batch_idx,
+                                int *num_points_per_voxel, float *mean, int mean_features,
+                                int mean_stride, int *row_count_dev, int rows_capacity,
+                                int *overflow_dev, int *voxel_num_host, void *workspace,
+                                size_t workspace_bytes, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  SF_CHECK_ARG(n >= 0 && f >= 3, "bad shape n=%d f=%d (need f >= 3)", n, f);
+  SF_CHECK_ARG(max_points >= 1, "max_points=%d: the hard path needs max_points >= 1 "
+               "(use sf_dynamic_voxelize for -1)", max_points);
+  SF_CHECK_ARG(max_voxels >= -1, "max_voxels=%d", max_voxels);
+  SF_CHECK_ARG(rows_capacity >= 0, "rows_capacity=%d", rows_capacity);
+  SF_CHECK_ARG((coors || rows_capacity == 0) && (coors_stride == 3 || coors_stride == 4),
+               "coors NULL or stride %d", coors_stride);
+  if (mean)
+    SF_CHECK_ARG(mean_features >= 1 && mean_features <= f && mean_stride >= mean_features,
+                 "mean_features=%d mean_stride=%d f=%d", mean_features, mean_stride, f);
+  VoxParams vp;
+  int rc = make_params(voxel_size, coors_range, &vp);
+  if (rc != SF_OK) return rc;
+  VoxWorkspace w = carve(workspace, n, max_points);
+  if (!workspace || workspace_bytes < w.bytes) {
+    sf_set_error("workspace too small: %zu < %zu bytes", workspace_bytes, w.bytes);
+    return SF_ERR_WORKSPACE;
+  }
+  SF_CHECK_ARG(n == 0 || points, "points is NULL");
+
+  const long long n_lists = w.cap * (long long)max_points;
+  hipLaunchKernelGGL(vox_fill_kernel, dim3(sf_grid(n_lists, kThreads)), dim3(kThreads), 0, st,
+                     w.keys, w.cap, w.lists, n_lists, w.misc, (const int *)row_count_dev);
+  SF_CHECK_LAUNCH();
+  if (n > 0) {
+    hipLaunchKernelGGL(vox_insert_kernel, dim3(sf_grid(n, kThreads)), dim3(kThreads), 0, st, points,
+                       n, f, vp, max_points, w.keys, (uint32_t)(w.cap - 1), w.lists, w.pslot,
+                       w.misc);
+    SF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(vox_count_kernel, dim3(w.nblk), dim3(kThreads), 0, st, n, max_points,
+                       (const int *)w.pslot, (const int *)w.lists, w.bsum);
+    SF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(vox_assign_kernel, dim3(w.nblk), dim3(kThreads), 0, st, n, max_points,
+                       max_voxels, vp, (const int *)w.pslot, (const int *)w.lists,
+                       (const uint32_t *)w.keys, (const int *)w.bsum, w.nblk, w.vox_slot, coors,
+                       coors_stride, batch_idx, rows_capacity, w.misc, row_count_dev, overflow_dev);
+    SF_CHECK_LAUNCH();
+    long long bound_v = (max_voxels >= 0 && max_voxels < n) ? max_voxels : n;
+    if (voxels) {
+      hipLaunchKernelGGL(vox_write_kernel, dim3(sf_grid(bound_v * max_points * f, kThreads)),
+                         dim3(kThreads), 0, st, points, f, max_points, (const int *)w.lists,
+                         (const int *)w.vox_slot, (const int *)w.misc, voxels);
+      SF_CHECK_LAUNCH();
+    }
+    if (num_points_per_voxel || mean) {
+      long long cols = mean ? mean_stride : 1;
+      hipLaunchKernelGGL(vox_reduce_kernel, dim3(sf_grid(bound_v * cols, kThreads)), dim3(kThreads),
+                         0, st, points, f, max_points, (const int *)w.lists,
+                         (const int *)w.vox_slot, (const int *)w.misc, num_points_per_voxel, mean,
+                         mean_features, mean_stride);
+      SF_CHECK_LAUNCH();
+    }
+  }
+  if (voxel_num_host) {
+    SF_CHECK_HIP(hipMemcpyAsync(voxel_num_host, w.misc + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+    SF_CHECK_HIP(hipStreamSynchronize(st));
+  }
+  return SF_OK;
+}
+
+extern "C" int sf_voxel_mean(const float *voxels, const int *num_points_per_voxel, const int *m_dev,
+                             int m_bound, int max_points, int f, int num_features, float *out,
+                             int out_stride, void *stream) {
+  SF_CHECK_ARG(m_bound >= 0 && max_points >= 1 && f >= 1 && num_features >= 1 &&
+                   num_features <= f && out_stride >= num_features,
+               "bad voxel_mean shape");
+  if (m_bound == 0) return SF_OK;
+  SF_CHECK_ARG(voxels && num_points_per_voxel && out, "NULL tensor pointer");
+  hipLaunchKernelGGL(voxel_mean_kernel, dim3(sf_grid((long long)m_bound * out_stride, kThreads)),
+                     dim3(kThreads), 0, (hipStream_t)stream, voxels, num_points_per_voxel, m_dev,
+                     m_bound, max_points, f, num_features, out, out_stride);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}

@@ -1,0 +1,524 @@
+"""Sparse-convolution operator API on MI355X: the surface the reference re-exports from
+spconv (mmdet3d/ops/spconv/__init__.py:21-46) -- SparseConvTensor, SparseModule,
+SparseSequential, SubMConv3d, SparseConv3d -- plus the functional layer of the vendored
+spconv 1.x (mmdet3d/ops/spconv/ops.py:46-126): get_indice_pairs, indice_conv.
+
+Everything numeric runs in libsparsefusion_hip.so.  The rulebook is kept in output-major form
+(neighbour table) on the device and only converted to the reference's (K,2,N) pair tensors
+when somebody asks for them.
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+
+
+def _triple(v, name='value'):
+    if isinstance(v, (list, tuple)):
+        if len(v) != 3:
+            raise ValueError(f'{name} must have 3 entries, got {v}')
+        return [int(x) for x in v]
+    return [int(v)] * 3
+
+
+def get_conv_output_size(input_size, kernel_size, stride, padding, dilation):
+    """ops/spconv/ops.py:20-30."""
+    out = []
+    for i in range(len(input_size)):
+        size = (input_size[i] + 2 * padding[i] - dilation[i] * (kernel_size[i] - 1) - 1) \
+            // stride[i] + 1
+        out.append(1 if kernel_size[i] == -1 else size)
+    return out
+
+
+# ------------------------------------------------------------------ device-side structures
+
+class CoordSet:
+    """One active set: indices (N,4) int32 (b,z,y,x) on the device, its coordinate hash and the
+    neighbour tables already derived from it (so SubM layers that share geometry share work;
+    the reference rebuilds an identical rulebook for every un-keyed SubM conv)."""
+
+    def __init__(self, indices, spatial_shape, batch_size, hash_table=None):
+        self.indices = indices
+        self.spatial_shape = [int(s) for s in spatial_shape]
+        self.batch_size = int(batch_size)
+        self._hash = hash_table
+        self.rulebooks = {}
+
+    @property
+    def n(self):
+        return self.indices.shape[0]
+
+    def hash(self):
+        if self._hash is None:
+            L = _lib.lib()
+            dev = self.indices.device
+            cap = L.sf_hash_capacity(max(self.n, 1))
+            keys = torch.empty(cap, dtype=torch.int32, device=dev)
+            vals = torch.empty(cap, dtype=torch.int32, device=dev)
+            flag = torch.zeros(1, dtype=torch.int32, device=dev)
+            _lib.check(L.sf_hash_build(_lib.ptr(self.indices), None, self.n,
+                                       _lib.i3(self.spatial_shape), self.batch_size,
+                                       keys.data_ptr(), vals.data_ptr(), cap, flag.data_ptr(),
+                                       _lib.stream(dev)))
+            self._hash = (keys, vals, cap)
+        return self._hash
+
+
+class Rulebook:
+    """Neighbour table nbr (K, stride) int32 + what it connects."""
+
+    def __init__(self, nbr, K, in_coords, out_coords, ksize, stride, padding, subm):
+        self.nbr = nbr
+        self.K = K
+        self.in_coords = in_coords
+        self.out_coords = out_coords
+        self.ksize, self.stride, self.padding, self.subm = ksize, stride, padding, subm
+        self._pairs = None
+
+    @property
+    def k_first(self):
+        return (self.K - 1) // 2 if self.subm else -1
+
+    def indice_pairs(self):
+        """(indice_pairs (K,2,N_in) int32, indice_num (K,) int32) in the reference layout."""
+        if self._pairs is None:
+            L = _lib.lib()
+            n_in, n_out = self.in_coords.n, self.out_coords.n
+            dev = self.nbr.device
+            pairs = torch.empty((self.K, 2, n_in), dtype=torch.int32, device=dev)
+            num = torch.empty((self.K,), dtype=torch.int32, device=dev)
+            wsb = L.sf_export_indice_pairs_workspace(self.K, n_in)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            _lib.check(L.sf_export_indice_pairs(self.nbr.data_ptr(), self.nbr.shape[1], self.K,
+                                                None, n_out, n_in, pairs.data_ptr(),
+                                                num.data_ptr(), ws.data_ptr(), wsb,
+                                                _lib.stream(dev)))
+            self._pairs = (pairs, num)
+        return self._pairs
+
+
+def build_rulebook(coords, ksize, stride, padding, dilation, subm):
+    """Rulebook of one conv over `coords` (ops.get_indice_pairs semantics, spconv_ops.h:27-141)."""
+    L = _lib.lib()
+    ks, st, pd, dl = _triple(ksize), _triple(stride), _triple(padding), _triple(dilation)
+    if any(d != 1 for d in dl):
+        raise NotImplementedError('dilation != 1 is not supported (SparseEncoder never uses it)')
+    if subm:
+        st, pd = [1, 1, 1], [k // 2 for k in ks]  # spconv_ops.h:76-79
+    key = (tuple(ks), tuple(st), tuple(pd), bool(subm))
+    if key in coords.rulebooks:
+        return coords.rulebooks[key]
+    K = ks[0] * ks[1] * ks[2]
+    if K > 27:
+        raise NotImplementedError('kernel volume > 27 is not supported')
+    dev = coords.indices.device
+    stream = _lib.stream(dev)
+    keys, vals, cap = coords.hash()
+    if subm:
+        out_coords = coords
+    else:
+        out_shape = get_conv_output_size(coords.spatial_shape, ks, st, pd, dl)
+        vol = coords.batch_size * out_shape[0] * out_shape[1] * out_shape[2]
+        reach = 1
+        for k, s in zip(ks, st):
+            reach *= (k + s - 1) // s  # outputs one input can touch per dim
+        bound = max(min(coords.n * reach, vol), 1)
+        ocap = L.sf_hash_capacity(bound)
+        okeys = torch.empty(ocap, dtype=torch.int32, device=dev)
+        ovals = torch.empty(ocap, dtype=torch.int32, device=dev)
+        outids = torch.empty((bound, 4), dtype=torch.int32, device=dev)
+        cnt = torch.zeros(2, dtype=torch.int32, device=dev)  # [n_out, overflow]
+        wsb = L.sf_conv_output_set_workspace(coords.n, ocap)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        _lib.check(L.sf_conv_output_set(_lib.ptr(coords.indices), None, coords.n,
+                                        coords.batch_size, _lib.i3(out_shape), _lib.i3(ks),
+                                        _lib.i3(st), _lib.i3(pd), okeys.data_ptr(),
+                                        ovals.data_ptr(), ocap, outids.data_ptr(), bound,
+                                        cnt.data_ptr(), cnt.data_ptr() + 4, ws.data_ptr(), wsb,
+                                        stream))
+        n_out, overflow = cnt.tolist()  # the one host sync of a strided conv in module mode
+        if overflow:
+            raise RuntimeError('sparse conv output set overflowed its table')
+        out_coords = CoordSet(outids[:n_out], out_shape, coords.batch_size, (okeys, ovals, ocap))
+    n_out = out_coords.n
+    stride_rows = max(n_out, 1)
+    nbr = torch.empty((K, stride_rows), dtype=torch.int32, device=dev)
+    _lib.check(L.sf_neighbor_table(_lib.ptr(out_coords.indices), None, n_out, coords.batch_size,
+                                   _lib.i3(coords.spatial_shape), _lib.i3(ks), _lib.i3(st),
+                                   _lib.i3(pd), keys.data_ptr(), vals.data_ptr(), cap,
+                                   1 if subm else 0, nbr.data_ptr(), stride_rows, stream))
+    rb = Rulebook(nbr, K, coords, out_coords, ks, st, pd, bool(subm))
+    coords.rulebooks[key] = rb
+    return rb
+
+
+class IndiceData(tuple):
+    """indice_dict entry.  Unpacks like the reference's 5-tuple
+    (outids, indices, indice_pairs, indice_pair_num, spatial_shape) (conv.py:169-172); the pair
+    tensors are exported from the neighbour table on first access."""
+
+    def __new__(cls, rulebook):
+        self = super().__new__(cls, ())
+        self.rulebook = rulebook
+        return self
+
+    def _fields(self):
+        rb = self.rulebook
+        pairs, num = rb.indice_pairs()
+        return (rb.out_coords.indices, rb.in_coords.indices, pairs, num,
+                rb.in_coords.spatial_shape)
+
+    def __iter__(self):
+        return iter(self._fields())
+
+    def __len__(self):
+        return 5
+
+    def __getitem__(self, i):
+        return self._fields()[i]
+
+
+class SparseConvTensor:
+    """structure.py:21-69 / spconv.pytorch.core.SparseConvTensor (2.x adds replace_feature)."""
+
+    def __init__(self, features, indices, spatial_shape, batch_size, grid=None):
+        self.features = features
+        if indices.dtype != torch.int32:
+            indices = indices.int()
+        self.indices = indices.contiguous()
+        self.spatial_shape = [int(s) for s in spatial_shape]
+        self.batch_size = int(batch_size)  # accepts a 0-d tensor (detectors/sparsefusion.py:121)
+        self.indice_dict = {}
+        self.grid = grid
+        self._coords = None
+
+    def coords(self):
+        if self._coords is None:
+            self._coords = CoordSet(self.indices, self.spatial_shape, self.batch_size)
+        return self._coords
+
+    @property
+    def spatial_size(self):
+        return int(np.prod(self.spatial_shape))
+
+    def find_indice_pair(self, key):
+        if key is None:
+            return None
+        return self.indice_dict.get(key)
+
+    def replace_feature(self, features):
+        out = SparseConvTensor(features, self.indices, self.spatial_shape, self.batch_size,
+                               self.grid)
+        out.indice_dict = self.indice_dict
+        out._coords = self._coords
+        return out
+
+    def dense(self, channels_first=True):
+        """(B, C, D, H, W) (or (B, D, H, W, C)); structure.py:55-64."""
+        feats = self.features
+        _lib.require(feats, torch.float32, 'features')
+        C = feats.shape[1]
+        D, H, W = self.spatial_shape
+        out = torch.empty((self.batch_size, C, D, H, W), dtype=feats.dtype, device=feats.device)
+        _lib.check(_lib.lib().sf_dense_bev(_lib.ptr(feats.contiguous()), _lib.ptr(self.indices),
+                                           None, feats.shape[0], C, self.batch_size, D, H, W,
+                                           out.data_ptr(), _lib.stream(feats.device)))
+        if channels_first:
+            return out
+        return out.permute(0, 2, 3, 4, 1).contiguous()
+
+    @property
+    def sparity(self):
+        return self.indices.shape[0] / np.prod(self.spatial_shape) / self.batch_size
+
+
+# ------------------------------------------------------------------ functional layer
+
+def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padding=0, dilation=1,
+                     out_padding=0, subm=False, transpose=False, grid=None):
+    """ops/spconv/ops.py:46-105 -> (outids, indice_pairs (K,2,N), indice_pair_num (K,)).
+    Output rows in the CPU reference's first-touch order, pairs in input-row order."""
+    if transpose:
+        raise NotImplementedError('transposed (inverse) convolution is outside the hot path')
+    coords = CoordSet(indices.int().contiguous(), spatial_shape, batch_size)
+    rb = build_rulebook(coords, ksize, stride, padding, dilation, subm)
+    pairs, num = rb.indice_pairs()
+    return rb.out_coords.indices, pairs, num
+
+
+def pack_filters(weight_kio):
+    """(K, Cin, Cout) fp32 on the device -> MFMA fragment order for sf_sparse_conv_f32."""
+    L = _lib.lib()
+    K, cin, cout = weight_kio.shape
+    cp = L.sf_conv_padded_cin(cin)
+    if cp < 0:
+        raise RuntimeError(f'unsupported in_channels {cin}')
+    packed = torch.empty(K * max(cp, 16) * cout, dtype=torch.float32, device=weight_kio.device)
+    _lib.check(L.sf_pack_filters_f32(_lib.ptr(weight_kio.contiguous()), K, cin, cout,
+                                     packed.data_ptr(), _lib.stream(weight_kio.device)))
+    return packed
+
+
+def _padded_features(features, cin):
+    L = _lib.lib()
+    cp = L.sf_conv_padded_cin(cin)
+    if cp < 0:
+        raise RuntimeError(f'unsupported in_channels {cin}')
+    if features.shape[1] == cp:
+        return features.contiguous(), cp
+    dst = torch.empty((features.shape[0], cp), dtype=torch.float32, device=features.device)
+    _lib.check(L.sf_pad_channels_f32(_lib.ptr(features.contiguous()), features.shape[1],
+                                     dst.data_ptr(), cp, None, features.shape[0],
+                                     _lib.stream(features.device)))
+    return dst, cp
+
+
+def sparse_conv(features, packed_filters, cin, cout, rulebook, scale=None, shift=None,
+                residual=None, relu=False):
+    """One fused layer: conv (+ folded BN scale/shift) (+ residual) (+ ReLU)."""
+    L = _lib.lib()
+    _lib.require(features, torch.float32, 'features')
+    if features.shape[0] != rulebook.in_coords.n:
+        raise RuntimeError('features rows do not match the rulebook input set')
+    x, cp = _padded_features(features, cin)
+    n_out = rulebook.out_coords.n
+    out = torch.empty((n_out, cout), dtype=torch.float32, device=features.device)
+    if residual is not None:
+        if residual.shape != out.shape:
+            raise RuntimeError('residual shape mismatch')
+        residual = residual.contiguous()
+    _lib.check(L.sf_sparse_conv_f32(
+        _lib.ptr(x), cp, rulebook.nbr.data_ptr(), rulebook.nbr.shape[1], rulebook.K,
+        rulebook.k_first, _lib.ptr(packed_filters), cout, _lib.ptr(scale), _lib.ptr(shift),
+        _lib.ptr(residual), 1 if relu else 0, out.data_ptr(), None, n_out,
+        _lib.stream(features.device)))
+    return out
+
+
+def indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_out, inverse=False,
+                subm=False):
+    """ops/spconv/ops.py:108-126 (indice_conv_fp32): filters (kD,kH,kW,Cin,Cout), rulebook in
+    the reference's pair format (e.g. straight from get_indice_pairs)."""
+    if inverse:
+        raise NotImplementedError('inverse convolution is outside the hot path')
+    L = _lib.lib()
+    cin, cout = filters.shape[-2], filters.shape[-1]
+    K, _, Lp = indice_pairs.shape
+    dev = features.device
+    n_out = int(num_activate_out)
+    stride_rows = max(n_out, 1)
+    nbr = torch.empty((K, stride_rows), dtype=torch.int32, device=dev)
+    _lib.check(L.sf_indice_pairs_to_table(_lib.ptr(indice_pairs.int().contiguous()),
+                                          _lib.ptr(indice_pair_num.int().contiguous()), K, Lp,
+                                          n_out, nbr.data_ptr(), stride_rows, _lib.stream(dev)))
+    packed = pack_filters(filters.reshape(K, cin, cout).float())
+    x, cp = _padded_features(features, cin)
+    out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
+    k_first = (K - 1) // 2 if subm else -1
+    _lib.check(L.sf_sparse_conv_f32(_lib.ptr(x), cp, nbr.data_ptr(), stride_rows, K, k_first,
+                                    packed.data_ptr(), cout, None, None, None, 0, out.data_ptr(),
+                                    None, n_out, _lib.stream(dev)))
+    return out
+
+
+# ------------------------------------------------------------------ modules
+
+class SparseModule(nn.Module):
+    """Marker base class: modules that take a SparseConvTensor (modules.py:25-28)."""
+
+
+def fold_bn(bn):
+    """Eval-mode BatchNorm1d -> per-channel (scale, shift): scale = gamma/sqrt(var+eps),
+    shift = beta - mean*scale (the correct fold, tools/misc/fuse_conv_bn.py:18-21)."""
+    var, mean = bn.running_var.float(), bn.running_mean.float()
+    scale = torch.rsqrt(var + bn.eps)
+    if bn.weight is not None:
+        scale = scale * bn.weight.float()
+    shift = -mean * scale
+    if bn.bias is not None:
+        shift = shift + bn.bias.float()
+    return scale.contiguous(), shift.contiguous()
+
+
+def _bn_foldable(m):
+    return (isinstance(m, nn.BatchNorm1d) and not m.training and m.running_mean is not None and
+            m.running_var is not None)
+
+
+class SparseConvolution(SparseModule):
+    """conv.py:48-204.  Parameter layout is spconv-2's (Cout, kD, kH, kW, Cin), the layout the
+    reference's checkpoints hold (write_spconv2.py:46-47); a spconv-1 tensor
+    (kD,kH,kW,Cin,Cout) in a state dict is permuted on load."""
+
+    def __init__(self, ndim, in_channels, out_channels, kernel_size=3, stride=1, padding=0,
+                 dilation=1, groups=1, bias=True, subm=False, output_padding=0, transposed=False,
+                 inverse=False, indice_key=None, fused_bn=False):
+        super().__init__()
+        if ndim != 3:
+            raise NotImplementedError('only 3-D sparse convolution is on the hot path')
+        if groups != 1 or transposed or inverse:
+            raise NotImplementedError('groups/transposed/inverse convolution is out of scope')
+        self.ndim = ndim
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.kernel_size = _triple(kernel_size, 'kernel_size')
+        self.conv1x1 = int(np.prod(self.kernel_size)) == 1
+        self.stride = _triple(stride, 'stride')
+        self.padding = _triple(padding, 'padding')
+        self.dilation = _triple(dilation, 'dilation')
+        self.output_padding = _triple(output_padding, 'output_padding')
+        self.transposed, self.inverse, self.groups = transposed, inverse, groups
+        self.subm = subm
+        self.indice_key = indice_key
+        self.fused_bn = fused_bn
+        self.weight = nn.Parameter(torch.empty(out_channels, *self.kernel_size, in_channels))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self._packed = None
+        self._packed_key = None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in = self.in_channels * int(np.prod(self.kernel_size))
+            bound = 1 / math.sqrt(fan_in)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        w = state_dict.get(prefix + 'weight')
+        v2 = (self.out_channels, *self.kernel_size, self.in_channels)
+        v1 = (*self.kernel_size, self.in_channels, self.out_channels)
+        if w is not None and tuple(w.shape) != v2 and tuple(w.shape) == v1:
+            state_dict[prefix + 'weight'] = w.permute(4, 0, 1, 2, 3).contiguous()
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def packed_filters(self):
+        key = (self.weight._version, self.weight.device, self.weight.data_ptr())
+        if self._packed is None or self._packed_key != key:
+            K = int(np.prod(self.kernel_size))
+            w = self.weight.detach().float().permute(1, 2, 3, 4, 0).reshape(
+                K, self.in_channels, self.out_channels).contiguous()
+            self._packed = pack_filters(w)
+            self._packed_key = key
+        return self._packed
+
+    def rulebook_for(self, input):
+        datas = input.find_indice_pair(self.indice_key)
+        if self.indice_key is not None and datas is not None:
+            return datas.rulebook
+        rb = build_rulebook(input.coords(), self.kernel_size, self.stride, self.padding,
+                            self.dilation, self.subm)
+        if self.indice_key is not None:
+            input.indice_dict[self.indice_key] = IndiceData(rb)
+        return rb
+
+    def forward_fused(self, input, scale=None, shift=None, residual=None, relu=False):
+        assert isinstance(input, SparseConvTensor)
+        rb = self.rulebook_for(input)
+        if self.bias is not None:
+            b = self.bias.detach().float()
+            shift = b if shift is None else shift + b * scale
+            if scale is None:
+                scale = torch.ones_like(b)
+        feats = sparse_conv(input.features, self.packed_filters(), self.in_channels,
+                            self.out_channels, rb, scale, shift, residual, relu)
+        out = SparseConvTensor(feats, rb.out_coords.indices, rb.out_coords.spatial_shape,
+                               input.batch_size, input.grid)
+        out.indice_dict = input.indice_dict
+        out._coords = rb.out_coords
+        return out
+
+    def forward(self, input):
+        return self.forward_fused(input)
+
+
+class SparseConv3d(SparseConvolution):
+    """conv.py:233-256."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, indice_key=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation,
+                         groups, bias, indice_key=indice_key)
+
+
+class SubMConv3d(SparseConvolution):
+    """conv.py:404-428."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, indice_key=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation,
+                         groups, bias, True, indice_key=indice_key)
+
+
+class SparseSequential(SparseModule):
+    """modules.py:55-137: nn.Sequential that threads a SparseConvTensor through SparseModules and
+    applies plain nn.Modules to `.features`.  On top of that contract, a
+    conv -> BatchNorm1d(eval) [-> ReLU] run is executed as ONE fused kernel."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        if len(args) == 1 and isinstance(args[0], OrderedDict):
+            for key, module in args[0].items():
+                self.add_module(key, module)
+        else:
+            for idx, module in enumerate(args):
+                self.add_module(str(idx), module)
+        for name, module in kwargs.items():
+            if name in self._modules:
+                raise ValueError('name exists.')
+            self.add_module(name, module)
+
+    def __getitem__(self, idx):
+        if not (-len(self) <= idx < len(self)):
+            raise IndexError('index {} is out of range'.format(idx))
+        if idx < 0:
+            idx += len(self)
+        return list(self._modules.values())[idx]
+
+    def __len__(self):
+        return len(self._modules)
+
+    def add(self, module, name=None):
+        if name is None:
+            name = str(len(self._modules))
+            if name in self._modules:
+                raise KeyError('name exists')
+        self.add_module(name, module)
+
+    def forward(self, input):
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, SparseConvolution) and isinstance(input, SparseConvTensor) and \
+                    i + 1 < len(mods) and _bn_foldable(mods[i + 1]):
+                scale, shift = fold_bn(mods[i + 1])
+                relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+                input = m.forward_fused(input, scale, shift, None, relu)
+                i += 3 if relu else 2
+            elif isinstance(m, SparseModule):
+                assert isinstance(input, SparseConvTensor)
+                input = m(input)
+                i += 1
+            else:
+                if isinstance(input, SparseConvTensor):
+                    if input.indices.shape[0] != 0:
+                        input = input.replace_feature(m(input.features))
+                else:
+                    input = m(input)
+                i += 1
+        return input
+
+
+from .registry import CONV_LAYERS  # noqa: E402
+
+CONV_LAYERS.register_module('SparseConv3d', module=SparseConv3d, force=True)
+CONV_LAYERS.register_module('SubMConv3d', module=SubMConv3d, force=True)
