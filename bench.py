@@ -1,0 +1,285 @@
+#!/usr/bin/env python3
+"""Headline benchmark: LiDAR frames/s through voxelize + HardSimpleVFE mean + SparseEncoder
+forward (BASELINE.json metric) on synthetic nuScenes-shaped sweeps, fp32, one process per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one frame (BASELINE.json configs[1]: single nuScenes-shaped frame, fp32) through the
+whole hot path, points already resident in HBM, replayed from a HIP graph.  Frames shard by
+rank (frame ids rank*F .. rank*F+F-1), no collective on the data path; only the
+elapsed time is max-reduced over ranks.  Rank 0 prints ONE JSON line.
+
+Also reported on that line:
+  roofline     -- the conv instantiation that takes the most time per frame: algorithmic
+                  flops (2*P*Cin*Cout) or bytes (P*Cin*4 + N_out*Cout*4*(1+res) + P*8) per
+                  launch / its mean launch duration measured with HIP events on the launch
+                  stream; peak from MI355X_MICROARCH.md (fp32 MFMA 157.3 TFLOP/s, HBM 8 TB/s).
+  cpu_baseline -- the CPU oracle (a port of the reference's CPU path, oracle/) on the same
+                  frame 0, timed on this box's host cores (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from sparsefusion_amd import configs, synth  # noqa: E402
+from sparsefusion_amd.pipeline import LidarBackbone  # noqa: E402
+from sparsefusion_amd.sparse_encoder import SparseEncoder  # noqa: E402
+
+PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+
+
+def build_backbone(workload, dev, batch, max_points):
+    cfg = configs.NUSC if workload == 'nusc' else configs.WAYMO
+    ecfg = dict(cfg['pts_middle_encoder'])
+    ecfg.pop('type')
+    wcfg = {k: ecfg[k] for k in ('base_channels', 'output_channels', 'encoder_channels',
+                                 'block_type') if k in ecfg}
+    sd = synth.encoder_state_dict(2024, ecfg['in_channels'], **wcfg)
+    enc = SparseEncoder(**ecfg)
+    enc.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    enc = enc.to(dev).eval()
+    bb = LidarBackbone(cfg['pts_voxel_layer'], enc, dev, max_points, batch_size=batch)
+    return cfg, ecfg, sd, enc, bb
+
+
+def layer_work(bb):
+    """Per-layer algorithmic work of the LAST enqueued frame (SURVEY 8d / BASELINE.md sec. 4)."""
+    counts = bb.counts.tolist()
+    pairs = {}
+    for i, rb in enumerate(bb.rulebooks):
+        n = counts[rb['dst']]
+        pairs[i] = int((rb['nbr'][:, :n] >= 0).sum().item())
+    rows = []
+    for lay in bb.layers:
+        rb = lay.rb
+        i = bb.rulebooks.index(rb)
+        P, n_out = pairs[i], counts[rb['dst']]
+        cin = lay.cin
+        res = 1 if lay.residual_from == 'add' else 0
+        rows.append(dict(cin=cin, cout=lay.cout, subm=rb['subm'], K=rb['K'], pairs=P, n_out=n_out,
+                         flops=2.0 * P * cin * lay.cout,
+                         bytes=P * cin * 4.0 + n_out * lay.cout * 4.0 * (1 + res) + P * 8.0))
+    return rows, counts
+
+
+def time_layers(bb, pts, vf, iters=5):
+    """Mean launch duration of every conv layer, HIP events on the launch stream (eager)."""
+    import sparsefusion_amd._lib as _lib
+    L = _lib.lib()
+    real = L.sf_sparse_conv_f32
+    evs = []
+
+    class Shim:
+        def __getattr__(self, name):
+            return getattr(L, name)
+
+    def wrapped(*a):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = real(*a)
+        e1.record()
+        evs.append((e0, e1))
+        return rc
+
+    shim = Shim()
+    shim.__dict__['sf_sparse_conv_f32'] = wrapped
+    nl = len(bb.layers)
+    acc = np.zeros(nl)
+    old = bb.L
+    bb.L = shim
+    try:
+        for _ in range(iters):
+            evs.clear()
+            bb.enqueue(pts, vf)
+            torch.cuda.synchronize()
+            acc += np.array([a.elapsed_time(b) for a, b in evs])
+    finally:
+        bb.L = old
+    return acc / iters  # ms per layer
+
+
+def cpu_baseline(cfg, ecfg, sd, points, workload):
+    """The oracle (port of the reference's CPU path) on one frame; returns frames/s."""
+    from oracle import oracle as O
+    O.lib()
+    vl = cfg['pts_voxel_layer']
+    mv = vl['max_voxels'][1] if isinstance(vl['max_voxels'], (tuple, list)) else vl['max_voxels']
+    t0 = time.perf_counter()
+    v, c, n = O.hard_voxelize(points, vl['voxel_size'], vl['point_cloud_range'],
+                              vl['max_num_points'], mv)
+    t1 = time.perf_counter()
+    if workload == 'nusc':
+        feats = O.vfe_mean(v, n, ecfg['in_channels'])
+    else:
+        feats = np.random.default_rng(7).normal(0, 1, (c.shape[0], ecfg['in_channels'])) \
+            .astype(np.float32)
+    wcfg = {k: ecfg[k] for k in ('base_channels', 'output_channels', 'encoder_channels',
+                                 'encoder_paddings', 'block_type') if k in ecfg}
+    bev = O.sparse_encoder_forward(sd, feats, O.batch_coors([c]), 1, ecfg['sparse_shape'],
+                                   ecfg['in_channels'], **wcfg)
+    t2 = time.perf_counter()
+    return dict(value=round(1.0 / (t2 - t0), 4), unit='frames/s', cores=int(O.lib().sfo_num_threads()),
+                kind='port',
+                sample=f'1 full frame (frame 0, {points.shape[0]} points -> {c.shape[0]} voxels): '
+                       f'voxelize {t1 - t0:.2f} s + VFE/SparseEncoder {t2 - t1:.2f} s; OpenMP on the '
+                       f'GEMM rows only, rest single-threaded as in the reference'), bev
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--workload', default='nusc', choices=['nusc', 'waymo'])
+    ap.add_argument('--frames', type=int, default=4, help='distinct synthetic frames per rank')
+    ap.add_argument('--batch', type=int, default=1, help='frames per step (samples per batch)')
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--detail', default='', help='write per-layer timing/roofline JSON here')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+
+    gen = synth.nuscenes_frame if args.workload == 'nusc' else synth.waymo_frame
+    B = args.batch
+    host_frames = [gen(rank * args.frames * B + i) for i in range(args.frames * B)]
+    max_pts = max(p.shape[0] for p in host_frames)
+    cfg, ecfg, sd, enc, bb = build_backbone(args.workload, dev, B, max_pts)
+    frames = [[torch.from_numpy(host_frames[f * B + b]).to(dev) for b in range(B)]
+              for f in range(args.frames)]
+    vf = None
+    if args.workload == 'waymo':  # learned 64-ch VFE is outside this path: seeded N(0,1) features
+        g = torch.Generator(device='cpu').manual_seed(7)
+        vf = torch.randn((bb.sets[0]['bound'], ecfg['in_channels']), generator=g).to(dev)
+
+    with torch.no_grad():
+        if args.no_graph:
+            steps = [(lambda f=f: bb.enqueue(f, vf)) for f in frames]
+        else:
+            graphs = [bb.capture(f, vf) for f in frames]
+            steps = [g.replay for g in graphs]
+        for i in range(args.warmup):
+            steps[i % len(steps)]()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            steps[i % len(steps)]()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+
+        # ---- roofline of the dominant conv kernel (rank 0), outside the timed region -------
+        roofline, detail = None, None
+        if rank == 0:
+            ms = time_layers(bb, frames[0], vf)
+            bb.enqueue(frames[0], vf)
+            torch.cuda.synchronize()
+            work, counts = layer_work(bb)
+            res = bb.results()
+            if res['overflow']:
+                raise SystemExit('overflow flag set: a bound was exceeded')
+            groups = {}
+            for w, t in zip(work, ms):
+                gkey = (w['cin'], w['cout'])
+                g_ = groups.setdefault(gkey, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+                g_['ms'] += t
+                g_['flops'] += w['flops']
+                g_['bytes'] += w['bytes']
+                g_['launches'] += 1
+                w['ms'] = float(t)
+            dom = max(groups, key=lambda k: groups[k]['ms'])
+            gd = groups[dom]
+            avg_s = gd['ms'] / gd['launches'] * 1e-3
+            fl, by = gd['flops'] / gd['launches'], gd['bytes'] / gd['launches']
+            t_mfma, t_hbm = fl / (PEAK_F32_MFMA_TFLOPS * 1e12), by / (PEAK_HBM_GBS * 1e9)
+            if t_mfma >= t_hbm:
+                ach = fl / avg_s / 1e12
+                roofline = dict(bound='mfma', achieved=round(ach, 3), peak=PEAK_F32_MFMA_TFLOPS,
+                                unit='TFLOP/s', frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                                traffic=None)
+            else:
+                ach = by / avg_s / 1e9
+                roofline = dict(bound='hbm', achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit='GB/s',
+                                frac=round(ach / PEAK_HBM_GBS, 4), traffic=None)
+            roofline['kernel'] = f'sparse_conv_f32_kernel<{dom[0] if dom[0] > 8 else 8},{dom[1]}>'
+            roofline['launches_per_frame'] = gd['launches']
+            roofline['avg_launch_us'] = round(avg_s * 1e6, 2)
+            roofline['algorithmic_flops_per_launch'] = fl
+            roofline['algorithmic_bytes_per_launch'] = by
+            tot_fl, tot_by = sum(w['flops'] for w in work), sum(w['bytes'] for w in work)
+            detail = dict(counts=counts[:-1], layers=work, conv_ms_per_frame=float(ms.sum()),
+                          frame_flops=tot_fl, frame_bytes=tot_by,
+                          groups={f'{k[0]}x{k[1]}': v for k, v in groups.items()},
+                          workspace_bytes=bb.memory_bytes())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * args.steps * B / elapsed
+    if rank == 0:
+        line = {
+            'metric': 'LiDAR frames/sec (voxelize+SparseEncoder fwd)',
+            'value': round(value, 2), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': ('nuScenes-shaped 10-sweep frame (sparsefusion_nusc_voxel_LC_r50: '
+                                    '0.075 m voxels, sparse_shape 41x1440x1440), fp32, single frame '
+                                    'per step' if args.workload == 'nusc' else
+                                    'Waymo-shaped stress frame (transfusion_waymo_voxel_L: 0.1 m '
+                                    'voxels, 41x1504x1504, 64-ch encoder input), fp32'),
+                       'frames_per_step': B, 'distinct_frames_per_rank': args.frames,
+                       'points_per_frame': int(np.mean([p.shape[0] for p in host_frames])),
+                       'voxels_frame0': detail['counts'][0] if detail else None,
+                       'hip_graph': not args.no_graph, 'sharding': 'frames by rank, no collective'},
+            'roofline': roofline,
+        }
+        if detail:
+            line['frame_algorithmic_gflop'] = round(detail['frame_flops'] / 1e9, 2)
+            line['frame_algorithmic_gbyte'] = round(detail['frame_bytes'] / 1e9, 3)
+        if world == 1 and not args.no_cpu_baseline:
+            cb, bev_cpu = cpu_baseline(cfg, ecfg, sd, host_frames[0], args.workload)
+            line['cpu_baseline'] = cb
+            if args.workload == 'nusc' and B == 1:  # same frame: the GPU result must match it
+                with torch.no_grad():
+                    got = bb.enqueue(frames[0], vf).cpu().numpy()
+                err = float(np.abs(got - bev_cpu).max() / max(np.abs(bev_cpu).max(), 1e-30))
+                line['parity_vs_cpu_rel_err'] = err
+        else:
+            line['cpu_baseline'] = None
+        if args.detail and detail:
+            with open(args.detail, 'w') as f:
+                json.dump(detail, f, indent=1)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,309 @@
+"""`LidarBackbone`: the whole hot path as ONE sync-free enqueue on one HIP stream.
+
+    points (list of (N_i,F) f32 per sample)
+      -> sf_hard_voxelize (+ fused HardSimpleVFE mean, batch index, row append)   per sample
+      -> coordinate phase: hash tables + neighbour tables of every layer geometry
+      -> feature phase: 21 fused conv+BN(+residual)+ReLU kernels
+      -> sf_dense_bev                                  -> (B, C*D, H, W) f32
+
+It is what detectors/sparsefusion.py:114-122 does through Voxelization / HardSimpleVFE /
+SparseEncoder (voxelize -> pts_voxel_encoder -> pts_middle_encoder), with the data-dependent
+row counts left in device memory: every buffer is sized once from host-known upper bounds, no
+kernel argument depends on a count, so nothing waits on the host and the whole frame can be
+captured in a HIP graph (`capture()`), as a launch-bound inner loop should be on MI355X.
+
+The modules in voxelize.py / sparse_encoder.py give the same numbers through the reference's
+object API; this class takes its layer list and weights FROM a SparseEncoder module.
+"""
+import torch
+from torch import nn
+
+from . import _lib, spconv
+from .sparse_block import SparseBasicBlock
+from .sparse_encoder import SparseEncoder
+
+
+class _Layer:
+    __slots__ = ('conv', 'bn', 'relu', 'residual_from', 'rb', 'cin', 'cout', 'packed', 'scale',
+                 'shift', 'in_buf', 'out_buf')
+
+
+def _flatten_encoder(enc):
+    """SparseEncoder module tree -> [(conv, bn, relu, identity_role)] in forward
+    order (sparse_encoder.py:112-121, sparse_block.py:116-139).  Only the post-activation
+    ('conv','norm','act') order with eval-mode BatchNorm1d is fusable."""
+    out = []
+
+    def convmodule(seq):
+        mods = list(seq)
+        if not (len(mods) == 3 and isinstance(mods[0], spconv.SparseConvolution) and
+                isinstance(mods[1], nn.BatchNorm1d) and isinstance(mods[2], nn.ReLU)):
+            raise NotImplementedError('LidarBackbone fuses conv->BN->ReLU modules only')
+        out.append((mods[0], mods[1], True, None))
+
+    convmodule(enc.conv_input)
+    for stage in enc.encoder_layers:
+        for blk in stage:
+            if isinstance(blk, SparseBasicBlock):
+                out.append((blk.conv1, blk.norm1, True, 'save'))    # block input = identity
+                out.append((blk.conv2, blk.norm2, True, 'add'))     # + identity before ReLU
+            else:
+                convmodule(blk)
+    convmodule(enc.conv_out)
+    return out
+
+
+class LidarBackbone:
+
+    def __init__(self, voxel_layer_cfg, encoder, device, max_points, batch_size=1,
+                 materialize_voxels=True, training=False):
+        assert isinstance(encoder, SparseEncoder)
+        L = self.L = _lib.lib()
+        self.dev = torch.device(device)
+        self.B = int(batch_size)
+        self.max_points_in = int(max_points)
+        cfg = voxel_layer_cfg
+        self.voxel_size = list(cfg['voxel_size'])
+        self.pc_range = list(cfg['point_cloud_range'])
+        self.mp = int(cfg['max_num_points'])
+        mv = cfg['max_voxels']
+        mv = mv if isinstance(mv, (tuple, list)) else (mv, mv)
+        self.mv = int(mv[0] if training else mv[1])
+        self.materialize = materialize_voxels
+        self.enc = encoder
+        self.in_channels = encoder.in_channels
+        self.F = None  # point feature count, fixed at first call
+        dev = self.dev
+
+        def i32(*shape):
+            return torch.empty(shape, dtype=torch.int32, device=dev)
+
+        def f32(*shape):
+            return torch.empty(shape, dtype=torch.float32, device=dev)
+
+        # ---- geometry plan: coordinate sets and rulebooks -------------------------------
+        flat = _flatten_encoder(encoder)
+        shape = [int(s) for s in encoder.sparse_shape]
+        n0 = self.B * self.mv
+        self.sets = [dict(shape=shape, bound=n0)]          # coordinate set 0 = voxels
+        self.rulebooks = []                                # dicts, deduplicated
+        self.layers = []
+        cur = 0
+        rb_index = {}
+        for conv, bn, relu, res in flat:
+            ks, dl = conv.kernel_size, conv.dilation
+            if any(d != 1 for d in dl):
+                raise NotImplementedError('dilation != 1')
+            if conv.subm:
+                st, pd = [1, 1, 1], [k // 2 for k in ks]
+            else:
+                st, pd = conv.stride, conv.padding
+            key = (cur, tuple(ks), tuple(st), tuple(pd), bool(conv.subm))
+            if key not in rb_index:
+                if conv.subm:
+                    dst = cur
+                else:
+                    s_in = self.sets[cur]
+                    oshape = spconv.get_conv_output_size(s_in['shape'], ks, st, pd, dl)
+                    reach = 1
+                    for k, s in zip(ks, st):
+                        reach *= (k + s - 1) // s
+                    vol = self.B * oshape[0] * oshape[1] * oshape[2]
+                    self.sets.append(dict(shape=oshape, bound=max(min(s_in['bound'] * reach, vol), 1)))
+                    dst = len(self.sets) - 1
+                rb_index[key] = len(self.rulebooks)
+                self.rulebooks.append(dict(src=cur, dst=dst, ks=list(ks), st=list(st), pd=list(pd),
+                                           subm=bool(conv.subm), K=ks[0] * ks[1] * ks[2]))
+            rb = self.rulebooks[rb_index[key]]
+            lay = _Layer()
+            lay.conv, lay.bn, lay.relu, lay.residual_from = conv, bn, relu, res
+            lay.rb, lay.cin, lay.cout = rb, conv.in_channels, conv.out_channels
+            self.layers.append(lay)
+            cur = rb['dst']
+        self.out_set = cur
+        self.out_channels = self.layers[-1].cout
+
+        # ---- device buffers sized from the bounds ---------------------------------------
+        self.counts = torch.zeros(len(self.sets) + 1, dtype=torch.int32, device=dev)  # + overflow
+        for s in self.sets:
+            b = s['bound']
+            s['indices'] = i32(b, 4)
+            s['cap'] = L.sf_hash_capacity(b)
+            s['keys'] = i32(s['cap'])
+            s['vals'] = i32(s['cap'])
+        for rb in self.rulebooks:
+            nb = self.sets[rb['dst']]['bound']
+            rb['nbr'] = i32(rb['K'], nb)
+            rb['stride'] = nb
+        ws = 0
+        for rb in self.rulebooks:
+            if not rb['subm']:
+                ws = max(ws, L.sf_conv_output_set_workspace(self.sets[rb['src']]['bound'],
+                                                            self.sets[rb['dst']]['cap']))
+        self.rb_ws = torch.empty(max(ws, 256), dtype=torch.uint8, device=dev)
+        self.rb_ws_bytes = max(ws, 256)
+        vws = L.sf_hard_voxelize_workspace(self.max_points_in, self.mp)
+        self.vox_ws = torch.empty(vws, dtype=torch.uint8, device=dev)
+        self.vox_ws_bytes = vws
+        self.cin_pad = L.sf_conv_padded_cin(self.in_channels)
+        self.mean = f32(n0, self.cin_pad)                  # fused VFE output, zero padded columns
+        self.voxels = None                                  # allocated once F is known
+        self.num_points = i32(n0)
+        # feature buffers: three per coordinate set are enough for conv / block ping-pong
+        self.fbufs = {}
+        for lay in self.layers:
+            d = lay.rb['dst']
+            self.fbufs.setdefault((d, lay.cout), [f32(self.sets[d]['bound'], lay.cout)
+                                                  for _ in range(3)])
+        D, H, W = self.sets[self.out_set]['shape']
+        self.bev = f32(self.B, self.out_channels * D, H, W)
+        self.refresh_weights()
+
+    # ------------------------------------------------------------------
+    def refresh_weights(self):
+        """(Re)pack filters and fold BatchNorm from the SparseEncoder module's current tensors."""
+        for lay in self.layers:
+            if lay.bn.training:
+                raise RuntimeError('LidarBackbone needs eval-mode BatchNorm (call encoder.eval())')
+            lay.packed = lay.conv.packed_filters()
+            lay.scale, lay.shift = spconv.fold_bn(lay.bn)
+            if lay.conv.bias is not None:
+                lay.shift = (lay.shift + lay.conv.bias.detach().float() * lay.scale).contiguous()
+
+    def memory_bytes(self):
+        tot = 0
+        for t in self._tensors():
+            tot += t.numel() * t.element_size()
+        return tot
+
+    def _tensors(self):
+        for s in self.sets:
+            yield from (s['indices'], s['keys'], s['vals'])
+        for rb in self.rulebooks:
+            yield rb['nbr']
+        for bufs in self.fbufs.values():
+            yield from bufs
+        yield from (self.rb_ws, self.vox_ws, self.mean, self.num_points, self.bev)
+        if self.voxels is not None:
+            yield self.voxels
+
+    # ------------------------------------------------------------------
+    def enqueue(self, points_list, voxel_features=None):
+        """Enqueue one batch on the current stream; returns the (static) BEV tensor.  No host
+        synchronisation, no allocation after the first call: safe under graph capture.
+
+        voxel_features: optional (>= B*max_voxels, in_channels) f32 tensor used as the encoder
+        input instead of the fused per-voxel mean (configs whose voxel encoder is a learned VFE,
+        e.g. the Waymo config's 64-channel HardVFE, which is not part of this path)."""
+        L, dev = self.L, self.dev
+        st = _lib.stream(dev)
+        chk = _lib.check
+        if len(points_list) != self.B:
+            raise RuntimeError(f'expected {self.B} samples, got {len(points_list)}')
+        if self.F is None:
+            self.F = int(points_list[0].shape[1])
+            if self.materialize:
+                self.voxels = torch.empty((self.B * self.mv, self.mp, self.F), dtype=torch.float32,
+                                          device=dev)
+        cnt = self.counts
+        c0 = cnt.data_ptr()
+        ovf = c0 + 4 * len(self.sets)
+        self.counts.zero_()
+        s0 = self.sets[0]
+        if voxel_features is None and self.in_channels > self.F:
+            raise RuntimeError(f'encoder wants {self.in_channels} input channels but points have '
+                               f'{self.F} features: pass voxel_features')
+        nf = min(self.in_channels, self.F)
+        # ---- voxelize (+ mean, + batch index), samples append behind each other ----------
+        for b, pts in enumerate(points_list):
+            if pts.shape[0] > self.max_points_in or pts.shape[1] != self.F:
+                raise RuntimeError('point cloud larger than max_points or feature count changed')
+            _lib.require(pts, torch.float32, 'points')
+            chk(L.sf_hard_voxelize(
+                _lib.ptr(pts), pts.shape[0], self.F, _lib.f3(self.voxel_size),
+                _lib.f6(self.pc_range), self.mp, self.mv,
+                self.voxels.data_ptr() if self.materialize else None, s0['indices'].data_ptr(), 4,
+                b, self.num_points.data_ptr(), self.mean.data_ptr(), nf, self.cin_pad, c0,
+                s0['bound'], ovf, None, self.vox_ws.data_ptr(), self.vox_ws_bytes, st))
+        # ---- coordinate phase --------------------------------------------------------------
+        chk(L.sf_hash_build(s0['indices'].data_ptr(), c0, s0['bound'], _lib.i3(s0['shape']),
+                            self.B, s0['keys'].data_ptr(), s0['vals'].data_ptr(), s0['cap'], ovf,
+                            st))
+        for rb in self.rulebooks:
+            src, dst = self.sets[rb['src']], self.sets[rb['dst']]
+            n_src, n_dst = c0 + 4 * rb['src'], c0 + 4 * rb['dst']
+            if not rb['subm']:
+                chk(L.sf_conv_output_set(
+                    src['indices'].data_ptr(), n_src, src['bound'], self.B, _lib.i3(dst['shape']),
+                    _lib.i3(rb['ks']), _lib.i3(rb['st']), _lib.i3(rb['pd']), dst['keys'].data_ptr(),
+                    dst['vals'].data_ptr(), dst['cap'], dst['indices'].data_ptr(), dst['bound'],
+                    n_dst, ovf, self.rb_ws.data_ptr(), self.rb_ws_bytes, st))
+            chk(L.sf_neighbor_table(
+                dst['indices'].data_ptr(), n_dst, dst['bound'], self.B, _lib.i3(src['shape']),
+                _lib.i3(rb['ks']), _lib.i3(rb['st']), _lib.i3(rb['pd']), src['keys'].data_ptr(),
+                src['vals'].data_ptr(), src['cap'], 1 if rb['subm'] else 0, rb['nbr'].data_ptr(),
+                rb['stride'], st))
+        # ---- feature phase -----------------------------------------------------------------
+        x, x_ch = self.mean, self.cin_pad
+        if voxel_features is not None:
+            _lib.require(voxel_features, torch.float32, 'voxel_features')
+            if voxel_features.shape[0] < s0['bound'] or voxel_features.shape[1] != self.cin_pad:
+                raise RuntimeError('voxel_features must be (>= B*max_voxels, padded in_channels)')
+            _lib.ptr(voxel_features)
+            x = voxel_features
+        block_in = None
+        for lay in self.layers:
+            rb = lay.rb
+            bufs = self.fbufs[(rb['dst'], lay.cout)]
+            busy = {x.data_ptr()}
+            if block_in is not None:
+                busy.add(block_in.data_ptr())
+            out = next(t for t in bufs if t.data_ptr() not in busy)  # 3 buffers: always one free
+            residual = None
+            if lay.residual_from == 'save':
+                block_in = x
+            elif lay.residual_from == 'add':
+                residual = block_in
+            cp = L.sf_conv_padded_cin(lay.cin)
+            assert cp == x_ch, (cp, x_ch)
+            chk(L.sf_sparse_conv_f32(
+                x.data_ptr(), cp, rb['nbr'].data_ptr(), rb['stride'], rb['K'],
+                (rb['K'] - 1) // 2 if rb['subm'] else -1, lay.packed.data_ptr(), lay.cout,
+                lay.scale.data_ptr(), lay.shift.data_ptr(),
+                residual.data_ptr() if residual is not None else None, 1 if lay.relu else 0,
+                out.data_ptr(), c0 + 4 * rb['dst'], self.sets[rb['dst']]['bound'], st))
+            if residual is not None:
+                block_in = None
+            x, x_ch = out, lay.cout
+        # ---- dense BEV ---------------------------------------------------------------------
+        o = self.sets[self.out_set]
+        D, H, W = o['shape']
+        chk(L.sf_dense_bev(x.data_ptr(), o['indices'].data_ptr(), c0 + 4 * self.out_set, o['bound'],
+                           self.out_channels, self.B, D, H, W, self.bev.data_ptr(), st))
+        return self.bev
+
+    def __call__(self, points_list, voxel_features=None):
+        return self.enqueue(points_list, voxel_features)
+
+    # ------------------------------------------------------------------
+    def results(self):
+        """Host view of the last batch (one sync): counts per coordinate set, overflow flag and
+        the Voxelization outputs sliced to voxel_num."""
+        c = self.counts.tolist()
+        n0 = c[0]
+        out = dict(counts=c[:-1], overflow=c[-1], coors=self.sets[0]['indices'][:n0],
+                   num_points=self.num_points[:n0], voxel_features=self.mean[:n0, :self.in_channels],
+                   out_indices=self.sets[self.out_set]['indices'][:c[self.out_set]])
+        if self.voxels is not None:
+            out['voxels'] = self.voxels[:n0]
+        return out
+
+    def capture(self, points_list, voxel_features=None):
+        """Capture one batch into a HIP graph bound to these input tensors; returns the graph
+        (call .replay()).  The first (eager) call warms up lazy state."""
+        self.enqueue(points_list, voxel_features)
+        torch.cuda.synchronize(self.dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.enqueue(points_list, voxel_features)
+        return g

@@ -1,0 +1,82 @@
+"""The fused, sync-free LidarBackbone (voxelize + mean + SparseEncoder in one enqueue, counts on
+the device, optional HIP graph) against the CPU oracle and against the module-by-module path."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import (SMALL_RANGE, SMALL_SHAPE, SMALL_VOXEL, assert_close, small_points, to_dev,
+                     weight_cfg)
+from sparsefusion_amd.pipeline import LidarBackbone
+from sparsefusion_amd.voxel_encoder import HardSimpleVFE
+from sparsefusion_amd.voxelize import Voxelization
+from test_gpu_conv import make_encoder
+
+pytestmark = pytest.mark.gpu
+VL = dict(max_num_points=10, voxel_size=SMALL_VOXEL, max_voxels=(3000, 6000),
+          point_cloud_range=SMALL_RANGE)
+
+
+def oracle_bev(oracle, sd, cfg, frames, mp, mv):
+    vox, coors = [], []
+    for p in frames:
+        v, c, n = oracle.hard_voxelize(p, SMALL_VOXEL, SMALL_RANGE, mp, mv)
+        vox.append(oracle.vfe_mean(v, n, 5))
+        coors.append(c)
+    feats, coors4 = np.concatenate(vox, 0), oracle.batch_coors(coors)
+    bev = oracle.sparse_encoder_forward(sd, feats, coors4, len(frames), SMALL_SHAPE, 5,
+                                        **weight_cfg(cfg), encoder_paddings=cfg['encoder_paddings'])
+    return bev, feats, coors4
+
+
+@pytest.mark.parametrize('batch', [1, 3])
+def test_backbone_matches_oracle_and_modules(dev, oracle, batch):
+    enc, sd, cfg = make_encoder(dev, 5, 11)
+    frames = [small_points(200 + b, 3500 + 700 * b) for b in range(batch)]
+    bb = LidarBackbone(VL, enc, dev, max_points=8000, batch_size=batch)
+    pts = [to_dev(p, dev) for p in frames]
+    with torch.no_grad():
+        bev = bb(pts).clone()
+    res = bb.results()
+    assert res['overflow'] == 0
+    expect, feats, coors4 = oracle_bev(oracle, sd, cfg, frames, 10, 6000)
+    assert np.array_equal(res['coors'].cpu().numpy(), coors4)            # (b,z,y,x), batch order
+    assert_close(res['voxel_features'].cpu().numpy(), feats, 1e-6, 1e-7)  # fused mean
+    assert_close(bev.cpu().numpy(), expect, 1e-4)
+    # module-by-module path (reference object API) gives the same tensor
+    vox_layer, vfe = Voxelization(**{**VL, 'max_voxels': VL['max_voxels']}).eval(), HardSimpleVFE(5)
+    with torch.no_grad():
+        vs, cs, ns = zip(*[vox_layer(p) for p in pts])
+        f = vfe(torch.cat(vs), torch.cat(ns), None)
+        c4 = torch.cat([torch.nn.functional.pad(c, (1, 0), value=i) for i, c in enumerate(cs)])
+        bev2 = enc(f, c4, batch)
+    assert torch.equal(res['voxels'], torch.cat(vs))
+    assert torch.equal(res['num_points'], torch.cat(ns))
+    assert torch.allclose(bev, bev2, rtol=0, atol=0)   # same kernels, same order: identical
+
+
+def test_graph_replay_and_reuse_across_frames(dev, oracle):
+    enc, sd, cfg = make_encoder(dev, 5, 12)
+    bb = LidarBackbone(VL, enc, dev, max_points=8000, batch_size=1)
+    a, b = small_points(301, 5000), small_points(302, 2000)   # second frame smaller: stale state
+    pa, pb = [to_dev(a, dev)], [to_dev(b, dev)]
+    with torch.no_grad():
+        ga, gb = bb.capture(pa), bb.capture(pb)
+        for g, frame in ((ga, a), (gb, b), (ga, a)):
+            g.replay()
+            torch.cuda.synchronize()
+            expect, _, _ = oracle_bev(oracle, sd, cfg, [frame], 10, 6000)
+            assert_close(bb.bev.cpu().numpy(), expect, 1e-4)
+            assert bb.results()['overflow'] == 0
+
+
+def test_voxel_cap_inside_pipeline(dev, oracle):
+    enc, sd, cfg = make_encoder(dev, 5, 13)
+    vl = dict(VL, max_voxels=(500, 800))   # cap triggers: the reference's break semantics
+    bb = LidarBackbone(vl, enc, dev, max_points=8000, batch_size=2)
+    frames = [small_points(401, 4000), small_points(402, 300)]
+    with torch.no_grad():
+        bev = bb([to_dev(p, dev) for p in frames])
+    expect, feats, coors4 = oracle_bev(oracle, sd, cfg, frames, 10, 800)
+    res = bb.results()
+    assert np.array_equal(res['coors'].cpu().numpy(), coors4)
+    assert_close(bev.cpu().numpy(), expect, 1e-4)
