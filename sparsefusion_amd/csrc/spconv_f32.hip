@@ -14,12 +14,12 @@
 //
 // Algorithmic HBM bytes per layer:
 //   P*Cin*4 (gather) + N_out*Cout*4*(1+residual) (single write [+identity read]) + P*8 (indices)
+#include <stdlib.h>
+
 #include "sf_common.h"
 
 namespace {
 
-constexpr int kTM = 64;       // output rows per tile (= one wavefront for the ballot compaction)
-constexpr int kThreads = 256; // 4 waves
 constexpr int kMaxK = 27;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -39,27 +39,86 @@ struct ATile {
   __device__ static __forceinline__ int pos(int p, int c) { return c ^ ((p / R) & M); }
 };
 
-template <int CIN, int COUT>
-__global__ void __launch_bounds__(kThreads)
+// One 16-row block (or two at once: two independent accumulator chains keep the fp32 MFMA pipe
+// at its 32-cycle issue rate instead of the 40-cycle dependent latency) of compacted rows times
+// the wave's filter columns; the products are added into the LDS-resident output tile (plain
+// read-add-write: rows are unique per offset and offsets are separated by barriers; LDS float
+// atomics measured 2x slower end to end).
+template <int CIN, int NBW, int T, int NS, int OST>
+__device__ __forceinline__ void mma_blocks(const float *__restrict__ sa, float *__restrict__ s_out,
+                                           const unsigned char *__restrict__ dstk, int cnt,
+                                           const f32x4 (&b)[NBW][T], const int (&sbs)[NS], int col0,
+                                           int g, int ln) {
+  constexpr int CH = CIN / 4;
+  f32x4 acc[NS][NBW];
+  int dst[NS][4];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) acc[s][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int q = sbs[s] * 16 + g * 4 + r;
+      dst[s][r] = (q < cnt) ? (int)dstk[q] : -1;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    f32x4 a4[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int p = sbs[s] * 16 + ln;
+      a4[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (CIN >= 16 || g < CH)
+        a4[s] = *reinterpret_cast<const f32x4 *>(&sa[p * CIN + 4 * ATile<CIN>::pos(p, 4 * t + g)]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < NBW; ++i)
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+          acc[s][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s][j], b[i][t][j], acc[s][i], 0, 0, 0);
+  }
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (dst[s][r] >= 0) {
+#pragma unroll
+        for (int i = 0; i < NBW; ++i)
+          s_out[dst[s][r] * OST + col0 + i * 16 + ln] += acc[s][i][r];
+      }
+}
+
+// TM    maximum output rows per tile (64 or 128); the kernel sizes its tiles at run time so
+//       that every workgroup of the grid gets the same number of tiles (no tail round)
+// WAVES wavefronts per workgroup (4 or 8)
+// ABUF  LDS buffers for the gathered rows (2: one barrier per offset, 1: two barriers, less LDS)
+template <int CIN, int COUT, int TM, int WAVES, int ABUF>
+__global__ void __launch_bounds__(WAVES * 64)
 sparse_conv_f32_kernel(const float *__restrict__ feat, const int *__restrict__ nbr, int nbr_stride,
                        int K, int k_first, const float *__restrict__ wpk,
                        const float *__restrict__ scale, const float *__restrict__ shift,
                        const float *__restrict__ residual, int relu, float *__restrict__ out,
-                       const int *n_out_dev, int n_out_bound) {
+                       const int *n_out_dev, int n_out_bound, int balance) {
+  constexpr int NT = WAVES * 64;
   constexpr int CINP = CIN < 16 ? 16 : CIN;  // packed-weight K extent
   constexpr int T = CINP / 16;               // 16-channel groups = float4 B fragments per N block
   constexpr int CH = CIN / 4;
   constexpr int NB = COUT / 16;
-  constexpr int CG = NB < 4 ? NB : 4;        // wave groups along output columns
-  constexpr int NBW = NB / CG;               // N blocks per wave
-  constexpr int RG = 4 / CG;                 // wave groups along compact rows
-  constexpr int OST = COUT + 4;              // padded output-tile row stride (floats)
-  constexpr int GI = (kTM * CH + kThreads - 1) / kThreads;  // gather items per thread
+  constexpr int CG = NB < WAVES ? NB : WAVES;  // wave groups along output columns
+  constexpr int NBW = NB / CG;                 // N blocks per wave
+  constexpr int RG = WAVES / CG;               // wave groups along compact rows
+  constexpr int OST = COUT + 4;                // padded output-tile row stride (floats)
+  constexpr int GI = (TM * CH + NT - 1) / NT;  // gather items per thread
+  constexpr int HALVES = TM / 64;
+  constexpr int KPW = (kMaxK + WAVES - 1) / WAVES;  // offsets compacted per wave
 
-  __shared__ __attribute__((aligned(16))) float s_out[kTM * OST];
-  __shared__ __attribute__((aligned(16))) float s_a[2][kTM * CIN];
-  __shared__ int s_src[kMaxK][kTM];
-  __shared__ unsigned char s_dst[kMaxK][kTM];
+  __shared__ __attribute__((aligned(16))) float s_out[TM * OST];
+  __shared__ __attribute__((aligned(16))) float s_a[ABUF][TM * CIN];
+  __shared__ int s_src[kMaxK][TM];
+  __shared__ unsigned char s_dst[kMaxK][TM];
   __shared__ int s_cnt[kMaxK];
   __shared__ int s_order[kMaxK + 1];
 
@@ -69,22 +128,52 @@ sparse_conv_f32_kernel(const float *__restrict__ feat, const int *__restrict__ n
   const int n_out = load_n(n_out_dev, n_out_bound);
   const f32x4 *__restrict__ wp4 = reinterpret_cast<const f32x4 *>(wpk);
 
-  for (int tile = blockIdx.x; tile * kTM < n_out; tile += gridDim.x) {
-    const int row0 = tile * kTM;
+  // tile height: TM rows, or (SF_CONV_BALANCE=1) the largest height <= TM that gives every
+  // workgroup of the grid the same number of tiles
+  const int G = gridDim.x;
+  int tm = TM;
+  if (balance) {
+    const int rounds = (n_out + G * TM - 1) / (G * TM);
+    tm = rounds > 0 ? (n_out + G * rounds - 1) / (G * rounds) : TM;
+    if (tm < 32) tm = 32;
+    if (tm > TM) tm = TM;
+  }
+  const int tiles = (n_out + tm - 1) / tm;
+  for (int tile = blockIdx.x; tile < tiles; tile += G) {
+    const int row0 = tile * tm;
+    const int row_end = (row0 + tm < n_out) ? row0 + tm : n_out;
     // ---- setup: compact the tile's pairs per offset, clear the output tile --------------
-    for (int k = wave; k < K; k += 4) {
-      int o = row0 + lane;
-      int v = (o < n_out) ? nbr[(size_t)k * nbr_stride + o] : -1;
-      unsigned long long m = __ballot(v >= 0);
-      int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
-                                          __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-      if (v >= 0) {
-        s_src[k][pos] = v;
-        s_dst[k][pos] = (unsigned char)lane;
+    int nv[KPW][HALVES];
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+      const int k = wave + i * WAVES;
+#pragma unroll
+      for (int h = 0; h < HALVES; ++h) {
+        int o = row0 + h * 64 + lane;
+        nv[i][h] = (k < K && o < row_end) ? nbr[(size_t)k * nbr_stride + o] : -1;
       }
-      if (lane == 0) s_cnt[k] = __popcll(m);
     }
-    for (int i = tid; i < kTM * OST; i += kThreads) s_out[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+      const int k = wave + i * WAVES;
+      if (k < K) {
+        int base = 0;
+#pragma unroll
+        for (int h = 0; h < HALVES; ++h) {
+          int v = nv[i][h];
+          unsigned long long m = __ballot(v >= 0);
+          int pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                     __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+          if (v >= 0) {
+            s_src[k][pos] = v;
+            s_dst[k][pos] = (unsigned char)(h * 64 + lane);
+          }
+          base += __popcll(m);
+        }
+        if (lane == 0) s_cnt[k] = base;
+      }
+    }
+    for (int i = tid; i < TM * OST; i += NT) s_out[i] = 0.0f;
     __syncthreads();
     if (tid == 0) {  // visit order: k_first (SubM centre) then ascending, empty offsets skipped
       int no = 0;
@@ -97,19 +186,24 @@ sparse_conv_f32_kernel(const float *__restrict__ feat, const int *__restrict__ n
     const int n_order = s_order[kMaxK];
 
     f32x4 greg[GI];
-    // gather of the first offset
+    f32x4 bcur[NBW][T], bnext[NBW][T];
     if (n_order > 0) {
       const int k = s_order[0], cnt = s_cnt[k];
 #pragma unroll
+      for (int i = 0; i < NBW; ++i)
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+          bcur[i][t] = wp4[(((size_t)k * NB + (cg * NBW + i)) * T + t) * 64 + lane];
+#pragma unroll
       for (int m = 0; m < GI; ++m) {
-        int idx = tid + m * kThreads, p = idx / CH, c = idx % CH;
-        if (idx < kTM * CH && p < cnt)
+        int idx = tid + m * NT, p = idx / CH, c = idx % CH;
+        if (idx < TM * CH && p < cnt)
           greg[m] = *reinterpret_cast<const f32x4 *>(feat + (size_t)s_src[k][p] * CIN + 4 * c);
       }
 #pragma unroll
       for (int m = 0; m < GI; ++m) {
-        int idx = tid + m * kThreads, p = idx / CH, c = idx % CH;
-        if (idx < kTM * CH && p < cnt)
+        int idx = tid + m * NT, p = idx / CH, c = idx % CH;
+        if (idx < TM * CH && p < cnt)
           *reinterpret_cast<f32x4 *>(&s_a[0][p * CIN + 4 * ATile<CIN>::pos(p, c)]) = greg[m];
       }
     }
@@ -117,75 +211,62 @@ sparse_conv_f32_kernel(const float *__restrict__ feat, const int *__restrict__ n
 
     for (int kk = 0; kk < n_order; ++kk) {
       const int k = s_order[kk], cnt = s_cnt[k];
-      const int buf = kk & 1;
-      // (1) issue the next offset's gather loads (land in registers while we compute)
-      int cnt_next = 0, k_next = 0;
-      if (kk + 1 < n_order) {
-        k_next = s_order[kk + 1];
+      const int buf = (ABUF == 2) ? (kk & 1) : 0;
+      const bool more = kk + 1 < n_order;
+      // (1) issue the next offset's gather and filter loads (they land while we compute)
+      int cnt_next = 0;
+      if (more) {
+        const int k_next = s_order[kk + 1];
         cnt_next = s_cnt[k_next];
 #pragma unroll
         for (int m = 0; m < GI; ++m) {
-          int idx = tid + m * kThreads, p = idx / CH, c = idx % CH;
-          if (idx < kTM * CH && p < cnt_next)
-            greg[m] =
-                *reinterpret_cast<const f32x4 *>(feat + (size_t)s_src[k_next][p] * CIN + 4 * c);
+          int idx = tid + m * NT, p = idx / CH, c = idx % CH;
+          if (idx < TM * CH && p < cnt_next)
+            greg[m] = *reinterpret_cast<const f32x4 *>(
+                feat + (size_t)s_src[k_next][p] * CIN + 4 * c);
         }
-      }
-      // (2) this offset: B fragments from the packed filters (L2 resident), MFMA, add to tile
-      const int nsb = (cnt + 15) >> 4;
-      if (rg < nsb) {
-        f32x4 bfrag[NBW][T];
 #pragma unroll
         for (int i = 0; i < NBW; ++i)
 #pragma unroll
           for (int t = 0; t < T; ++t)
-            bfrag[i][t] = wp4[(((size_t)k * NB + (cg * NBW + i)) * T + t) * 64 + lane];
-        for (int sb = rg; sb < nsb; sb += RG) {
-          f32x4 acc[NBW];
-#pragma unroll
-          for (int i = 0; i < NBW; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          const int p = sb * 16 + ln;
-#pragma unroll
-          for (int t = 0; t < T; ++t) {
-            f32x4 a4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (CIN >= 16 || g < CH)
-              a4 = *reinterpret_cast<const f32x4 *>(
-                  &s_a[buf][p * CIN + 4 * ATile<CIN>::pos(p, 4 * t + g)]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-              for (int i = 0; i < NBW; ++i)
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], bfrag[i][t][j], acc[i], 0, 0, 0);
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            int q = sb * 16 + g * 4 + r;
-            if (q < cnt) {
-              int dst = s_dst[k][q];
-#pragma unroll
-              for (int i = 0; i < NBW; ++i)
-                s_out[dst * OST + (cg * NBW + i) * 16 + ln] += acc[i][r];
-            }
-          }
-        }
+            bnext[i][t] = wp4[(((size_t)k_next * NB + (cg * NBW + i)) * T + t) * 64 + lane];
       }
-      // (3) park the prefetched rows in the other LDS buffer
-      if (kk + 1 < n_order) {
+      // (2) this offset: MFMA over the compacted rows, products added into the LDS tile
+      const int nsb = (cnt + 15) >> 4;
+      int sb = rg;
+      for (; sb + RG < nsb; sb += 2 * RG) {
+        const int sbs[2] = {sb, sb + RG};
+        mma_blocks<CIN, NBW, T, 2, OST>(s_a[buf], s_out, s_dst[k], cnt, bcur, sbs, cg * NBW * 16, g,
+                                        ln);
+      }
+      if (sb < nsb) {
+        const int sbs[1] = {sb};
+        mma_blocks<CIN, NBW, T, 1, OST>(s_a[buf], s_out, s_dst[k], cnt, bcur, sbs, cg * NBW * 16, g,
+                                        ln);
+      }
+      // (3) park the prefetched rows in LDS for the next offset
+      if (ABUF == 1) __syncthreads();
+      if (more) {
 #pragma unroll
         for (int m = 0; m < GI; ++m) {
-          int idx = tid + m * kThreads, p = idx / CH, c = idx % CH;
-          if (idx < kTM * CH && p < cnt_next)
-            *reinterpret_cast<f32x4 *>(&s_a[buf ^ 1][p * CIN + 4 * ATile<CIN>::pos(p, c)]) = greg[m];
+          int idx = tid + m * NT, p = idx / CH, c = idx % CH;
+          if (idx < TM * CH && p < cnt_next)
+            *reinterpret_cast<f32x4 *>(
+                &s_a[ABUF == 2 ? (buf ^ 1) : 0][p * CIN + 4 * ATile<CIN>::pos(p, c)]) = greg[m];
         }
+#pragma unroll
+        for (int i = 0; i < NBW; ++i)
+#pragma unroll
+          for (int t = 0; t < T; ++t) bcur[i][t] = bnext[i][t];
       }
       __syncthreads();
     }
 
     // ---- epilogue: folded BN, residual, ReLU; one coalesced write per output row ---------
     constexpr int OC = COUT / 4;
-    for (int idx = tid; idx < kTM * OC; idx += kThreads) {
+    for (int idx = tid; idx < TM * OC; idx += NT) {
       int r = idx / OC, c = idx % OC, row = row0 + r;
-      if (row >= n_out) continue;
+      if (row >= row_end) continue;
       f32x4 v = *reinterpret_cast<const f32x4 *>(&s_out[r * OST + 4 * c]);
       if (scale) {
         f32x4 sc = *reinterpret_cast<const f32x4 *>(scale + 4 * c);
@@ -233,34 +314,105 @@ __global__ void pad_channels_kernel(const float *__restrict__ src, int cs, float
   }
 }
 
-template <int CIN, int COUT>
-int launch(const float *feat, const int *nbr, int nbr_stride, int K, int k_first, const float *wpk,
-           const float *scale, const float *shift, const float *residual, int relu, float *out,
-           const int *n_out_dev, int n_out_bound, hipStream_t st) {
-  int tiles = sf_div_up(n_out_bound, kTM);
-  int grid = tiles < 2048 ? tiles : 2048;
-  hipLaunchKernelGGL((sparse_conv_f32_kernel<CIN, COUT>), dim3(grid), dim3(kThreads), 0, st, feat,
-                     nbr, nbr_stride, K, k_first, wpk, scale, shift, residual, relu, out, n_out_dev,
-                     n_out_bound);
+struct ConvArgs {
+  const float *feat;
+  const int *nbr;
+  int nbr_stride, K, k_first;
+  const float *wpk, *scale, *shift, *residual;
+  int relu;
+  float *out;
+  const int *n_out_dev;
+  int n_out_bound;
+  hipStream_t st;
+};
+
+// Balanced tiling pays where a layer has only ~2 tiles per resident workgroup (the 128-channel
+// stage: 33k rows / 64 = 520 tiles on 256 CUs); SF_CONV_BALANCE=0/1 overrides for experiments.
+int env_balance(int dflt) {
+  static int v = -2;
+  if (v == -2) {
+    const char *e = getenv("SF_CONV_BALANCE");
+    v = e ? atoi(e) : -1;
+  }
+  return v < 0 ? dflt : (v & 1);
+}
+
+template <int CIN, int COUT, int TM, int WAVES, int ABUF>
+int launch(const ConvArgs &a) {
+  constexpr size_t lds = (size_t)TM * (COUT + 4) * 4 + (size_t)ABUF * TM * CIN * 4 +
+                         (size_t)kMaxK * TM * 5 + 256;
+  static_assert(lds <= 160 * 1024, "tile does not fit LDS");
+  // grid = what is resident at once (CUs x workgroups per CU), never more than the tiles
+  static int slots = 0;
+  if (slots == 0) {
+    int dev = 0, cus = 256, per_cu = 1;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            &per_cu, sparse_conv_f32_kernel<CIN, COUT, TM, WAVES, ABUF>, WAVES * 64, 0) != hipSuccess ||
+        per_cu < 1)
+      per_cu = 1;
+    int by_lds = (int)((160 * 1024) / lds);
+    if (per_cu > by_lds) per_cu = by_lds < 1 ? 1 : by_lds;
+    slots = cus * per_cu;
+  }
+  const int balance = env_balance((CIN >= 128 && COUT >= 128) ? 1 : 0);
+  int tiles = sf_div_up(a.n_out_bound, balance ? 32 : TM);
+  int cap = balance ? slots : 4096;
+  int grid = tiles < cap ? tiles : cap;
+  hipLaunchKernelGGL((sparse_conv_f32_kernel<CIN, COUT, TM, WAVES, ABUF>), dim3(grid),
+                     dim3(WAVES * 64), 0, a.st, a.feat, a.nbr, a.nbr_stride, a.K, a.k_first, a.wpk,
+                     a.scale, a.shift, a.residual, a.relu, a.out, a.n_out_dev, a.n_out_bound,
+                     balance);
   SF_CHECK_LAUNCH();
   return SF_OK;
 }
 
-template <int CIN>
-int dispatch_cout(int cout, const float *feat, const int *nbr, int nbr_stride, int K, int k_first,
-                  const float *wpk, const float *scale, const float *shift, const float *residual,
-                  int relu, float *out, const int *n_out_dev, int n_out_bound, hipStream_t st) {
-#define SF_CASE(CO)                                                                             \
-  case CO:                                                                                      \
-    return launch<CIN, CO>(feat, nbr, nbr_stride, K, k_first, wpk, scale, shift, residual, relu, \
-                           out, n_out_dev, n_out_bound, st);
-  switch (cout) {
-    SF_CASE(16)
-    SF_CASE(32)
-    SF_CASE(64)
-    SF_CASE(128)
+// Experiment hook: SF_CONV_CFG="tm,waves,abuf" overrides the per-shape default (read once).
+int env_cfg() {
+  static int cfg = -2;
+  if (cfg == -2) {
+    cfg = -1;
+    const char *e = getenv("SF_CONV_CFG");
+    int tm, w, ab;
+    if (e && sscanf(e, "%d,%d,%d", &tm, &w, &ab) == 3) cfg = tm * 100 + w * 10 + ab;
   }
-#undef SF_CASE
+  return cfg;
+}
+
+template <int CIN, int COUT>
+int launch_cfg(const ConvArgs &a) {
+  constexpr bool big = (CIN >= 32 && COUT >= 32);  // shapes that get the tuning variants
+  int cfg = env_cfg();
+  if (cfg < 0 || !big) cfg = (COUT >= 128) ? 6481 : (CIN >= 64 ? 6441 : 6442);  // measured best
+  if constexpr (big) {
+    switch (cfg) {
+      case 6442: return launch<CIN, COUT, 64, 4, 2>(a);
+      case 6482: return launch<CIN, COUT, 64, 8, 2>(a);
+      case 6441: return launch<CIN, COUT, 64, 4, 1>(a);
+      case 6481: return launch<CIN, COUT, 64, 8, 1>(a);
+      case 12881:
+        return launch<CIN, COUT, 128, 8, 1>(a);
+      case 12882:
+        if constexpr (CIN <= 64 && COUT <= 64) return launch<CIN, COUT, 128, 8, 2>(a);
+        return launch<CIN, COUT, 128, 8, 1>(a);
+    }
+    sf_set_error("unknown SF_CONV_CFG %d", cfg);
+    return SF_ERR_BAD_ARG;
+  } else {
+    return launch<CIN, COUT, 64, 4, 2>(a);
+  }
+}
+
+template <int CIN>
+int dispatch_cout(int cout, const ConvArgs &a) {
+  switch (cout) {
+    case 16: return launch_cfg<CIN, 16>(a);
+    case 32: return launch_cfg<CIN, 32>(a);
+    case 64: return launch_cfg<CIN, 64>(a);
+    case 128: return launch_cfg<CIN, 128>(a);
+  }
   sf_set_error("unsupported cout=%d (16, 32, 64 or 128)", cout);
   return SF_ERR_BAD_ARG;
 }
@@ -319,18 +471,15 @@ extern "C" int sf_sparse_conv_f32(const float *features_in, int cin_padded, cons
                    ((uintptr_t)w_packed & 15) == 0 && ((uintptr_t)residual & 15) == 0 &&
                    ((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0,
                "feature / filter / epilogue pointers must be 16-byte aligned");
-#define SF_CIN(CI)                                                                              \
-  case CI:                                                                                      \
-    return dispatch_cout<CI>(cout, features_in, nbr, nbr_stride, K, k_first, w_packed, scale,   \
-                             shift, residual, relu, out, n_out_dev, n_out_bound, st);
+  ConvArgs a{features_in, nbr, nbr_stride, K, k_first, w_packed, scale, shift, residual, relu, out,
+             n_out_dev, n_out_bound, st};
   switch (cin_padded) {
-    SF_CIN(8)
-    SF_CIN(16)
-    SF_CIN(32)
-    SF_CIN(64)
-    SF_CIN(128)
+    case 8: return dispatch_cout<8>(cout, a);
+    case 16: return dispatch_cout<16>(cout, a);
+    case 32: return dispatch_cout<32>(cout, a);
+    case 64: return dispatch_cout<64>(cout, a);
+    case 128: return dispatch_cout<128>(cout, a);
   }
-#undef SF_CIN
   sf_set_error("unsupported cin_padded=%d (8, 16, 32, 64 or 128; see sf_conv_padded_cin)",
                cin_padded);
   return SF_ERR_BAD_ARG;
