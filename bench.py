@@ -31,7 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from sparsefusion_amd import configs, synth  # noqa: E402
+from sparsefusion_amd import configs, sharding, synth  # noqa: E402
 from sparsefusion_amd.pipeline import LidarBackbone  # noqa: E402
 from sparsefusion_amd.sparse_encoder import SparseEncoder  # noqa: E402
 
@@ -162,7 +162,9 @@ def main():
 
     gen = synth.nuscenes_frame if args.workload == 'nusc' else synth.waymo_frame
     B = args.batch
-    host_frames = [gen(rank * args.frames * B + i) for i in range(args.frames * B)]
+    # weak scaling: a stream of world*frames*B frames dealt round-robin, rank r gets r, r+world, ...
+    ids = sharding.frames_for_rank(rank, world, world * args.frames * B)
+    host_frames = [gen(i) for i in ids]
     max_pts = max(p.shape[0] for p in host_frames)
     cfg, ecfg, sd, enc, bb = build_backbone(args.workload, dev, B, max_pts)
     frames = [[torch.from_numpy(host_frames[f * B + b]).to(dev) for b in range(B)]
@@ -192,10 +194,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+        elapsed = sharding.max_over_ranks(elapsed, dev)   # the only cross-rank traffic
 
         # ---- roofline of the dominant conv kernel (rank 0), outside the timed region -------
         roofline, detail = None, None

@@ -11,7 +11,7 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kItems = 4;                  // inputs per thread in the output-set scan
+constexpr int kItems = 1;                  // inputs per thread in the scans (latency-bound: favour parallelism)
 constexpr int kChunk = kThreads * kItems;
 
 struct Geo {
@@ -105,18 +105,25 @@ __global__ void outset_insert_kernel(const int *__restrict__ indices, const int 
 __global__ void __launch_bounds__(kThreads)
 outset_count_kernel(const int *__restrict__ indices, const int *n_dev, int n_bound, Geo g,
                     const uint32_t *__restrict__ keys, uint32_t mask,
-                    const int *__restrict__ first, int *__restrict__ bsum) {
+                    const int *__restrict__ first, int *__restrict__ bsum,
+                    unsigned *__restrict__ ftmask) {
   __shared__ int smem[17];
   const int n = load_n(n_dev, n_bound);
+  if (blockIdx.x * kChunk >= n) return;  // grid is sized from the bound; bsum beyond n is unused
   int c = 0;
   for (int e = 0; e < kItems; ++e) {
     int j = blockIdx.x * kChunk + threadIdx.x * kItems + e;
     if (j >= n) break;
     int4 ci = reinterpret_cast<const int4 *>(indices)[j];
+    unsigned fm = 0;  // bit k set: this input is the first toucher of its output under offset k
     for_each_output(ci, g, [&](int k, int oz, int oy, int ox) {
       int slot = sf_hash_find(keys, mask, lin_key(ci.x, oz, oy, ox, g.oshape));
-      if (slot >= 0 && first[slot] == j * g.K + k) ++c;
+      if (slot >= 0 && first[slot] == j * g.K + k) {
+        ++c;
+        fm |= 1u << k;
+      }
     });
+    ftmask[j] = fm;
   }
   int total = sf_block_sum(c, smem);
   if (threadIdx.x == 0) bsum[blockIdx.x] = total;
@@ -126,32 +133,33 @@ outset_count_kernel(const int *__restrict__ indices, const int *n_dev, int n_bou
 __global__ void __launch_bounds__(kThreads)
 outset_assign_kernel(const int *__restrict__ indices, const int *n_dev, int n_bound, Geo g,
                      const uint32_t *__restrict__ keys, uint32_t mask,
-                     const int *__restrict__ first, const int *__restrict__ bsum, int nblk,
+                     const unsigned *__restrict__ ftmask, const int *__restrict__ bsum, int nblk,
                      int *__restrict__ vals, int *__restrict__ outids, int outids_rows,
                      int *__restrict__ n_out_dev, int *overflow_dev) {
   __shared__ int smem[17];
   const int n = load_n(n_dev, n_bound);
+  if (blockIdx.x > 0 && blockIdx.x * kChunk >= n) return;
+  const int nblk_used = (n + kChunk - 1) / kChunk;  // only these blocks wrote bsum
   int before, all;
-  sf_block_prefix_of(bsum, nblk, blockIdx.x, smem, &before, &all);
+  sf_block_prefix_of(bsum, nblk_used < nblk ? nblk_used : nblk, blockIdx.x, smem, &before, &all);
   int c = 0;
   for (int e = 0; e < kItems; ++e) {
     int j = blockIdx.x * kChunk + threadIdx.x * kItems + e;
     if (j >= n) break;
-    int4 ci = reinterpret_cast<const int4 *>(indices)[j];
-    for_each_output(ci, g, [&](int k, int oz, int oy, int ox) {
-      int slot = sf_hash_find(keys, mask, lin_key(ci.x, oz, oy, ox, g.oshape));
-      if (slot >= 0 && first[slot] == j * g.K + k) ++c;
-    });
+    c += __popc(ftmask[j]);
   }
   int total;
   int row = before + sf_block_excl_scan(c, smem, &total);
   for (int e = 0; e < kItems; ++e) {
     int j = blockIdx.x * kChunk + threadIdx.x * kItems + e;
     if (j >= n) break;
+    const unsigned fm = ftmask[j];
+    if (fm == 0) continue;
     int4 ci = reinterpret_cast<const int4 *>(indices)[j];
     for_each_output(ci, g, [&](int k, int oz, int oy, int ox) {
-      int slot = sf_hash_find(keys, mask, lin_key(ci.x, oz, oy, ox, g.oshape));
-      if (slot >= 0 && first[slot] == j * g.K + k) {
+      if ((fm >> k) & 1u) {
+        int slot = sf_hash_find(keys, mask, lin_key(ci.x, oz, oy, ox, g.oshape));
+        if (slot < 0) return;
         if (row < outids_rows) {
           vals[slot] = row;
           reinterpret_cast<int4 *>(outids)[row] = make_int4(ci.x, oz, oy, ox);
@@ -340,7 +348,8 @@ extern "C" int sf_hash_build(const int *indices, const int *n_dev, int n_bound, 
 extern "C" size_t sf_conv_output_set_workspace(int n_bound, int out_capacity) {
   if (n_bound < 0 || out_capacity < 0) return 0;
   int nblk = sf_div_up(n_bound > 0 ? n_bound : 1, kChunk);
-  return align_up((size_t)out_capacity * 4) + align_up((size_t)nblk * 4);
+  return align_up((size_t)out_capacity * 4) + align_up((size_t)nblk * 4) +
+         align_up((size_t)(n_bound > 0 ? n_bound : 1) * 4);
 }
 
 extern "C" int sf_conv_output_set(const int *indices, const int *n_dev, int n_bound, int batch,
@@ -367,6 +376,7 @@ extern "C" int sf_conv_output_set(const int *indices, const int *n_dev, int n_bo
   int *first = (int *)workspace;
   int *bsum = (int *)((char *)workspace + align_up((size_t)out_capacity * 4));
   const int nblk = sf_div_up(n_bound > 0 ? n_bound : 1, kChunk);
+  unsigned *ftmask = (unsigned *)((char *)bsum + align_up((size_t)nblk * 4));
   const uint32_t mask = (uint32_t)(out_capacity - 1);
   hipLaunchKernelGGL(table_fill_kernel, dim3(sf_grid(out_capacity, kThreads)), dim3(kThreads), 0,
                      st, out_keys, first, out_capacity, out_vals, out_capacity, -1);
@@ -375,10 +385,10 @@ extern "C" int sf_conv_output_set(const int *indices, const int *n_dev, int n_bo
                      indices, n_dev, n_bound, g, out_keys, mask, first, overflow_dev);
   SF_CHECK_LAUNCH();
   hipLaunchKernelGGL(outset_count_kernel, dim3(nblk), dim3(kThreads), 0, st, indices, n_dev,
-                     n_bound, g, (const uint32_t *)out_keys, mask, (const int *)first, bsum);
+                     n_bound, g, (const uint32_t *)out_keys, mask, (const int *)first, bsum, ftmask);
   SF_CHECK_LAUNCH();
   hipLaunchKernelGGL(outset_assign_kernel, dim3(nblk), dim3(kThreads), 0, st, indices, n_dev,
-                     n_bound, g, (const uint32_t *)out_keys, mask, (const int *)first,
+                     n_bound, g, (const uint32_t *)out_keys, mask, (const unsigned *)ftmask,
                      (const int *)bsum, nblk, out_vals, outids, outids_rows, n_out_dev,
                      overflow_dev);
   SF_CHECK_LAUNCH();
@@ -402,7 +412,10 @@ extern "C" int sf_neighbor_table(const int *outids, const int *n_out_dev, int n_
   SF_CHECK_ARG(!identity_center || (g.K % 2 == 1), "identity_center needs an odd kernel volume");
   if (n_out_bound == 0) return SF_OK;
   SF_CHECK_ARG(outids, "outids is NULL");
-  hipLaunchKernelGGL(neighbor_table_kernel, dim3(sf_grid((long long)n_out_bound * g.K, kThreads)),
+  // lookup chains are latency-bound: one (offset, row) per thread where the bound allows it
+  long long nt_blocks = ((long long)n_out_bound * g.K + kThreads - 1) / kThreads;
+  if (nt_blocks > 32768) nt_blocks = 32768;
+  hipLaunchKernelGGL(neighbor_table_kernel, dim3((unsigned)(nt_blocks < 1 ? 1 : nt_blocks)),
                      dim3(kThreads), 0, st, outids, n_out_dev, n_out_bound, g, batch, in_keys,
                      in_vals, (uint32_t)(in_capacity - 1), identity_center, nbr, nbr_stride);
   SF_CHECK_LAUNCH();

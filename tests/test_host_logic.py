@@ -1,0 +1,77 @@
+"""Host-side logic that needs no GPU: module tree / state-dict keys, weight-layout handling,
+registry entry points, BN folding, LidarBackbone planning."""
+import numpy as np
+import torch
+
+from helpers import encoder_cfg, torch_state_dict, weight_cfg
+from sparsefusion_amd import registry, spconv, synth
+from sparsefusion_amd.sparse_block import SparseBasicBlock, make_sparse_convmodule
+from sparsefusion_amd.sparse_encoder import SparseEncoder
+from sparsefusion_amd.voxelize import Voxelization
+
+
+def test_state_dict_keys_match_reference_names():
+    cfg = encoder_cfg('nusc')
+    enc = SparseEncoder(**cfg)
+    keys = set(enc.state_dict().keys())
+    sd = synth.encoder_state_dict(0, 5, **weight_cfg(cfg))
+    assert keys == set(sd.keys())
+    assert 'encoder_layers.encoder_layer3.2.0.weight' in keys
+    assert 'encoder_layers.encoder_layer4.1.bn2.running_var' in keys
+    assert enc.state_dict()['conv_out.0.weight'].shape == (128, 3, 1, 1, 128)   # spconv-2 layout
+    enc.load_state_dict(torch_state_dict(sd))
+    conv = enc.encoder_layers.encoder_layer3[2][0]
+    assert isinstance(conv, spconv.SparseConv3d) and conv.padding == [0, 1, 1] and conv.stride == [2, 2, 2]
+    assert conv.indice_key == 'spconv3' and enc.conv_input[0].indice_key == 'subm1'
+    blk = enc.encoder_layers.encoder_layer1[0]
+    assert isinstance(blk, SparseBasicBlock) and blk.conv1.indice_key is None
+    assert blk.bn1.eps == 1e-3 and blk.bn1.momentum == 0.01
+
+
+def test_spconv1_weight_layout_is_permuted_on_load():
+    conv = spconv.SubMConv3d(4, 8, 3, bias=False)
+    w1 = torch.randn(3, 3, 3, 4, 8)                       # spconv-1 (kD,kH,kW,Cin,Cout)
+    conv.load_state_dict({'weight': w1})
+    assert torch.equal(conv.weight.data, w1.permute(4, 0, 1, 2, 3))
+    w2 = torch.randn(8, 3, 3, 3, 4)
+    conv.load_state_dict({'weight': w2})
+    assert torch.equal(conv.weight.data, w2)
+
+
+def test_conv_module_variant_and_registry():
+    enc = registry.build_middle_encoder(dict(type='SparseEncoder', in_channels=4,
+                                             sparse_shape=[41, 1600, 1408]))   # class defaults
+    stage2 = enc.encoder_layers.encoder_layer2
+    assert isinstance(stage2[0][0], spconv.SparseConv3d) and stage2[0][0].indice_key == 'spconv2'
+    assert isinstance(stage2[1][0], spconv.SubMConv3d) and stage2[1][0].indice_key == 'subm2'
+    assert enc.encoder_layers.encoder_layer4[0][0].padding == [0, 1, 1]
+    vfe = registry.build_voxel_encoder(dict(type='HardSimpleVFE', num_features=5))
+    assert vfe.num_features == 5
+    m = make_sparse_convmodule(4, 8, 3, 'k', conv_type='SubMConv3d',
+                               norm_cfg=dict(type='BN1d', eps=1e-3, momentum=0.01))
+    assert [type(x).__name__ for x in m] == ['SubMConv3d', 'BatchNorm1d', 'ReLU']
+    assert m[0].bias is None
+
+
+def test_fold_bn_equals_batchnorm_eval():
+    bn = torch.nn.BatchNorm1d(6, eps=1e-3).eval()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(); bn.running_mean.normal_()
+        bn.running_var.uniform_(0.5, 2.0)
+        x = torch.randn(10, 6)
+        scale, shift = spconv.fold_bn(bn)
+        assert torch.allclose(x * scale + shift, bn(x), rtol=1e-5, atol=1e-6)
+
+
+def test_voxelization_attributes():
+    v = Voxelization([0.075, 0.075, 0.2], [-54.0, -54.0, -5.0, 54.0, 54.0, 3.0], 10, (120000, 160000))
+    assert v.grid_size.tolist() == [1440, 1440, 40] and v.max_voxels == (120000, 160000)
+    assert [int(x) for x in v.pcd_shape] == [1, 1440, 1440]
+    assert Voxelization([1, 1, 1], [0, 0, 0, 2, 2, 2], 5, 7).max_voxels == (7, 7)
+    assert 'max_num_points=10' in repr(v)
+
+
+def test_conv_output_size_rule():
+    assert spconv.get_conv_output_size([41, 1440, 1440], [3] * 3, [2] * 3, [1] * 3, [1] * 3) == [21, 720, 720]
+    assert spconv.get_conv_output_size([11, 360, 360], [3] * 3, [2] * 3, [0, 1, 1], [1] * 3) == [5, 180, 180]
+    assert spconv.get_conv_output_size([5, 180, 180], [3, 1, 1], [2, 1, 1], [0] * 3, [1] * 3) == [2, 180, 180]
