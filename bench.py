@@ -7,7 +7,7 @@ forward (BASELINE.json metric) on synthetic nuScenes-shaped sweeps, fp32, one pr
 
 A step = one frame (BASELINE.json configs[1]: single nuScenes-shaped frame, fp32) through the
 whole hot path, points already resident in HBM, replayed from a HIP graph.  Frames shard by
-rank (frame ids rank*F .. rank*F+F-1), no collective on the data path; only the
+rank (round-robin over a stream of frames), no collective on the data path; only the
 elapsed time is max-reduced over ranks.  Rank 0 prints ONE JSON line.
 
 Also reported on that line:
@@ -144,6 +144,8 @@ def main():
     ap.add_argument('--workload', default='nusc', choices=['nusc', 'waymo'])
     ap.add_argument('--frames', type=int, default=4, help='distinct synthetic frames per rank')
     ap.add_argument('--batch', type=int, default=1, help='frames per step (samples per batch)')
+    ap.add_argument('--streams', type=int, default=1,
+                    help='frames in flight per GPU (each on its own HIP stream and workspace)')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--detail', default='', help='write per-layer timing/roofline JSON here')
@@ -167,28 +169,44 @@ def main():
     host_frames = [gen(i) for i in ids]
     max_pts = max(p.shape[0] for p in host_frames)
     cfg, ecfg, sd, enc, bb = build_backbone(args.workload, dev, B, max_pts)
+    # frames in flight: independent frames on independent streams fill each other's tail rounds
+    # and barrier bubbles; every stream has its own workspace, weights are shared
+    lanes = [bb] + [LidarBackbone(cfg['pts_voxel_layer'], enc, dev, max_pts, batch_size=B)
+                    for _ in range(args.streams - 1)]
+    streams = [torch.cuda.Stream(device=dev) for _ in lanes]
     frames = [[torch.from_numpy(host_frames[f * B + b]).to(dev) for b in range(B)]
               for f in range(args.frames)]
     vf = None
     if args.workload == 'waymo':  # learned 64-ch VFE is outside this path: seeded N(0,1) features
         g = torch.Generator(device='cpu').manual_seed(7)
         vf = torch.randn((bb.sets[0]['bound'], ecfg['in_channels']), generator=g).to(dev)
+    torch.cuda.synchronize()
 
     with torch.no_grad():
-        if args.no_graph:
-            steps = [(lambda f=f: bb.enqueue(f, vf)) for f in frames]
-        else:
-            graphs = [bb.capture(f, vf) for f in frames]
-            steps = [g.replay for g in graphs]
+        steps = []   # steps[i] = (stream, callable): frame i % frames on lane i % streams
+        for li, (lane, st) in enumerate(zip(lanes, streams)):
+            with torch.cuda.stream(st):
+                if args.no_graph:
+                    fns = [(lambda f=f, lane=lane: lane.enqueue(f, vf)) for f in frames]
+                else:
+                    fns = [lane.capture(f, vf).replay for f in frames]
+            steps.append((st, fns))
+        torch.cuda.synchronize()
+
+        def run(i):
+            st, fns = steps[i % len(steps)]
+            with torch.cuda.stream(st):
+                fns[(i // len(steps)) % len(fns)]()
+
         for i in range(args.warmup):
-            steps[i % len(steps)]()
+            run(i)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            steps[i % len(steps)]()
+            run(i)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -256,7 +274,7 @@ def main():
                        'frames_per_step': B, 'distinct_frames_per_rank': args.frames,
                        'points_per_frame': int(np.mean([p.shape[0] for p in host_frames])),
                        'voxels_frame0': detail['counts'][0] if detail else None,
-                       'hip_graph': not args.no_graph, 'sharding': 'frames by rank, no collective'},
+                       'hip_graph': not args.no_graph, 'frames_in_flight': args.streams, 'sharding': 'frames by rank, no collective'},
             'roofline': roofline,
         }
         if detail:

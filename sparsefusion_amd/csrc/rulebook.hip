@@ -174,34 +174,31 @@ outset_assign_kernel(const int *__restrict__ indices, const int *n_dev, int n_bo
   if (blockIdx.x == 0 && threadIdx.x == 0) *n_out_dev = all < outids_rows ? all : outids_rows;
 }
 
+// grid: x over output rows, y = kernel offset (uniform per block: its geometry is scalar work)
 __global__ void neighbor_table_kernel(const int *__restrict__ outids, const int *n_out_dev,
                                       int n_out_bound, Geo g, int batch,
                                       const uint32_t *__restrict__ keys,
                                       const int *__restrict__ vals, uint32_t mask,
                                       int identity_center, int *__restrict__ nbr, int nbr_stride) {
   const int n = load_n(n_out_dev, n_out_bound);
-  const long long total = (long long)n * g.K;
-  const int center = (g.K - 1) / 2;
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-       e += (long long)gridDim.x * blockDim.x) {
-    int k = (int)(e / n), o = (int)(e - (long long)k * n);
+  const int k = blockIdx.y;
+  const int k2 = k % g.ks[2], k01 = k / g.ks[2];
+  const int k1 = k01 % g.ks[1], k0 = k01 / g.ks[1];
+  const int d0 = k0 - g.pad[0], d1 = k1 - g.pad[1], d2 = k2 - g.pad[2];
+  const bool ident = identity_center && k == (g.K - 1) / 2;
+  int *__restrict__ col = nbr + (size_t)k * nbr_stride;
+  for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < n; o += gridDim.x * blockDim.x) {
     int res = -1;
-    if (identity_center && k == center) {
+    if (ident) {
       res = o;
     } else {
       int4 c = reinterpret_cast<const int4 *>(outids)[o];
-      int k2 = k % g.ks[2], k01 = k / g.ks[2];
-      int k1 = k01 % g.ks[1], k0 = k01 / g.ks[1];
-      int iz = c.y * g.st[0] - g.pad[0] + k0;
-      int iy = c.z * g.st[1] - g.pad[1] + k1;
-      int ix = c.w * g.st[2] - g.pad[2] + k2;
+      int iz = c.y * g.st[0] + d0, iy = c.z * g.st[1] + d1, ix = c.w * g.st[2] + d2;
       if (iz >= 0 && iz < g.ishape[0] && iy >= 0 && iy < g.ishape[1] && ix >= 0 &&
-          ix < g.ishape[2] && c.x >= 0 && c.x < batch) {
-        int slot = sf_hash_find(keys, mask, lin_key(c.x, iz, iy, ix, g.ishape));
-        if (slot >= 0) res = vals[slot];
-      }
+          ix < g.ishape[2] && c.x >= 0 && c.x < batch)
+        res = sf_hash_lookup(keys, vals, mask, lin_key(c.x, iz, iy, ix, g.ishape));
     }
-    nbr[(size_t)k * nbr_stride + o] = res;
+    col[o] = res;
   }
 }
 
@@ -413,11 +410,11 @@ extern "C" int sf_neighbor_table(const int *outids, const int *n_out_dev, int n_
   if (n_out_bound == 0) return SF_OK;
   SF_CHECK_ARG(outids, "outids is NULL");
   // lookup chains are latency-bound: one (offset, row) per thread where the bound allows it
-  long long nt_blocks = ((long long)n_out_bound * g.K + kThreads - 1) / kThreads;
-  if (nt_blocks > 32768) nt_blocks = 32768;
-  hipLaunchKernelGGL(neighbor_table_kernel, dim3((unsigned)(nt_blocks < 1 ? 1 : nt_blocks)),
-                     dim3(kThreads), 0, st, outids, n_out_dev, n_out_bound, g, batch, in_keys,
-                     in_vals, (uint32_t)(in_capacity - 1), identity_center, nbr, nbr_stride);
+  int nt_x = sf_div_up(n_out_bound, kThreads);
+  if (nt_x > 2048) nt_x = 2048;
+  hipLaunchKernelGGL(neighbor_table_kernel, dim3(nt_x, g.K), dim3(kThreads), 0, st, outids,
+                     n_out_dev, n_out_bound, g, batch, in_keys, in_vals,
+                     (uint32_t)(in_capacity - 1), identity_center, nbr, nbr_stride);
   SF_CHECK_LAUNCH();
   return SF_OK;
 }

@@ -44,24 +44,29 @@ struct ATile {
 // the wave's filter columns; the products are added into the LDS-resident output tile (plain
 // read-add-write: rows are unique per offset and offsets are separated by barriers; LDS float
 // atomics measured 2x slower end to end).
-template <int CIN, int NBW, int T, int NS, int OST>
+template <int CIN, int NBW, int T, int NS, int OST, int TM>
 __device__ __forceinline__ void mma_blocks(const float *__restrict__ sa, float *__restrict__ s_out,
                                            const unsigned char *__restrict__ dstk, int cnt,
                                            const f32x4 (&b)[NBW][T], const int (&sbs)[NS], int col0,
                                            int g, int ln) {
   constexpr int CH = CIN / 4;
-  f32x4 acc[NS][NBW];
+  // NS == 1: split the channel groups over two accumulators (even / odd t) so the single block
+  // still runs two independent MFMA chains; summed once at the end.
+  constexpr int NA = (NS == 1 && T >= 2) ? 2 : NS;
+  f32x4 acc[NA][NBW];
   int dst[NS][4];
 #pragma unroll
-  for (int s = 0; s < NS; ++s) {
+  for (int s = 0; s < NA; ++s)
 #pragma unroll
     for (int i = 0; i < NBW; ++i) acc[s][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
     for (int r = 0; r < 4; ++r) {
       int q = sbs[s] * 16 + g * 4 + r;
-      dst[s][r] = (q < cnt) ? (int)dstk[q] : -1;
+      int d = dstk[q < TM ? q : TM - 1];
+      dst[s][r] = (q < cnt) ? d : TM;  // padding rows land in the spare row TM of the tile
     }
-  }
 #pragma unroll
   for (int t = 0; t < T; ++t) {
     f32x4 a4[NS];
@@ -77,18 +82,29 @@ __device__ __forceinline__ void mma_blocks(const float *__restrict__ sa, float *
 #pragma unroll
       for (int i = 0; i < NBW; ++i)
 #pragma unroll
-        for (int s = 0; s < NS; ++s)
-          acc[s][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s][j], b[i][t][j], acc[s][i], 0, 0, 0);
+        for (int s = 0; s < NS; ++s) {
+          const int a = (NS == 1 && NA == 2) ? (t & 1) : s;
+          acc[a][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s][j], b[i][t][j], acc[a][i], 0, 0, 0);
+        }
   }
+  if (NS == 1 && NA == 2) {
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) acc[0][i] += acc[1][i];
+  }
+  float cur[NS][4][NBW];
 #pragma unroll
   for (int s = 0; s < NS; ++s)
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      if (dst[s][r] >= 0) {
 #pragma unroll
-        for (int i = 0; i < NBW; ++i)
-          s_out[dst[s][r] * OST + col0 + i * 16 + ln] += acc[s][i][r];
-      }
+      for (int i = 0; i < NBW; ++i) cur[s][r][i] = s_out[dst[s][r] * OST + col0 + i * 16 + ln];
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int i = 0; i < NBW; ++i)
+        s_out[dst[s][r] * OST + col0 + i * 16 + ln] = cur[s][r][i] + acc[s][i][r];
 }
 
 // TM    maximum output rows per tile (64 or 128); the kernel sizes its tiles at run time so
@@ -101,7 +117,8 @@ sparse_conv_f32_kernel(const float *__restrict__ feat, const int *__restrict__ n
                        int K, int k_first, const float *__restrict__ wpk,
                        const float *__restrict__ scale, const float *__restrict__ shift,
                        const float *__restrict__ residual, int relu, float *__restrict__ out,
-                       const int *n_out_dev, int n_out_bound, int balance) {
+                       const int *n_out_dev, int n_out_bound, int balance,
+                       unsigned long long *__restrict__ prof) {
   constexpr int NT = WAVES * 64;
   constexpr int CINP = CIN < 16 ? 16 : CIN;  // packed-weight K extent
   constexpr int T = CINP / 16;               // 16-channel groups = float4 B fragments per N block
@@ -112,10 +129,11 @@ sparse_conv_f32_kernel(const float *__restrict__ feat, const int *__restrict__ n
   constexpr int RG = WAVES / CG;               // wave groups along compact rows
   constexpr int OST = COUT + 4;                // padded output-tile row stride (floats)
   constexpr int GI = (TM * CH + NT - 1) / NT;  // gather items per thread
-  constexpr int HALVES = TM / 64;
+  constexpr int HALVES = (TM + 63) / 64;
+  constexpr bool EXACT = (TM * CH) % NT == 0;  // every thread owns GI whole gather items
   constexpr int KPW = (kMaxK + WAVES - 1) / WAVES;  // offsets compacted per wave
 
-  __shared__ __attribute__((aligned(16))) float s_out[TM * OST];
+  __shared__ __attribute__((aligned(16))) float s_out[(TM + 1) * OST];  // + spare row
   __shared__ __attribute__((aligned(16))) float s_a[ABUF][TM * CIN];
   __shared__ int s_src[kMaxK][TM];
   __shared__ unsigned char s_dst[kMaxK][TM];
@@ -139,7 +157,17 @@ sparse_conv_f32_kernel(const float *__restrict__ feat, const int *__restrict__ n
     if (tm > TM) tm = TM;
   }
   const int tiles = (n_out + tm - 1) / tm;
+  // diagnostic stamps (prof != NULL only in profiling runs): cycles of wave 0 per region
+  unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tk0 = 0, tr0 = 0;
+#define SF_STAMP() (prof ? (unsigned long long)__builtin_amdgcn_s_memtime() : 0ull)
+  if (prof) {
+    tk0 = __builtin_amdgcn_s_memtime();
+    tr0 = __builtin_amdgcn_s_memrealtime();
+  }
+
   for (int tile = blockIdx.x; tile < tiles; tile += G) {
+    unsigned long long ts = SF_STAMP();
     const int row0 = tile * tm;
     const int row_end = (row0 + tm < n_out) ? row0 + tm : n_out;
     // ---- setup: compact the tile's pairs per offset, clear the output tile --------------
@@ -197,19 +225,25 @@ sparse_conv_f32_kernel(const float *__restrict__ feat, const int *__restrict__ n
 #pragma unroll
       for (int m = 0; m < GI; ++m) {
         int idx = tid + m * NT, p = idx / CH, c = idx % CH;
-        if (idx < TM * CH && p < cnt)
-          greg[m] = *reinterpret_cast<const f32x4 *>(feat + (size_t)s_src[k][p] * CIN + 4 * c);
+        if (EXACT || idx < TM * CH)
+          greg[m] = *reinterpret_cast<const f32x4 *>(
+              feat + (size_t)s_src[k][p < cnt ? p : 0] * CIN + 4 * c);
       }
 #pragma unroll
       for (int m = 0; m < GI; ++m) {
         int idx = tid + m * NT, p = idx / CH, c = idx % CH;
-        if (idx < TM * CH && p < cnt)
+        if (EXACT || idx < TM * CH)
           *reinterpret_cast<f32x4 *>(&s_a[0][p * CIN + 4 * ATile<CIN>::pos(p, c)]) = greg[m];
       }
     }
     __syncthreads();
+    {
+      unsigned long long te = SF_STAMP();
+      pt[0] += te - ts;  // setup + first gather
+    }
 
     for (int kk = 0; kk < n_order; ++kk) {
+      unsigned long long t0 = SF_STAMP();
       const int k = s_order[kk], cnt = s_cnt[k];
       const int buf = (ABUF == 2) ? (kk & 1) : 0;
       const bool more = kk + 1 < n_order;
@@ -220,10 +254,12 @@ sparse_conv_f32_kernel(const float *__restrict__ feat, const int *__restrict__ n
         cnt_next = s_cnt[k_next];
 #pragma unroll
         for (int m = 0; m < GI; ++m) {
+          // rows past cnt_next are never consumed: they re-read list entry 0 (one cache line)
+          // so that the loads and LDS stores stay straight-line code
           int idx = tid + m * NT, p = idx / CH, c = idx % CH;
-          if (idx < TM * CH && p < cnt_next)
+          if (EXACT || idx < TM * CH)
             greg[m] = *reinterpret_cast<const f32x4 *>(
-                feat + (size_t)s_src[k_next][p] * CIN + 4 * c);
+                feat + (size_t)s_src[k_next][p < cnt_next ? p : 0] * CIN + 4 * c);
         }
 #pragma unroll
         for (int i = 0; i < NBW; ++i)
@@ -231,26 +267,29 @@ sparse_conv_f32_kernel(const float *__restrict__ feat, const int *__restrict__ n
           for (int t = 0; t < T; ++t)
             bnext[i][t] = wp4[(((size_t)k_next * NB + (cg * NBW + i)) * T + t) * 64 + lane];
       }
+      unsigned long long t1 = SF_STAMP();
       // (2) this offset: MFMA over the compacted rows, products added into the LDS tile
       const int nsb = (cnt + 15) >> 4;
       int sb = rg;
       for (; sb + RG < nsb; sb += 2 * RG) {
         const int sbs[2] = {sb, sb + RG};
-        mma_blocks<CIN, NBW, T, 2, OST>(s_a[buf], s_out, s_dst[k], cnt, bcur, sbs, cg * NBW * 16, g,
+        mma_blocks<CIN, NBW, T, 2, OST, TM>(s_a[buf], s_out, s_dst[k], cnt, bcur, sbs, cg * NBW * 16, g,
                                         ln);
       }
       if (sb < nsb) {
         const int sbs[1] = {sb};
-        mma_blocks<CIN, NBW, T, 1, OST>(s_a[buf], s_out, s_dst[k], cnt, bcur, sbs, cg * NBW * 16, g,
+        mma_blocks<CIN, NBW, T, 1, OST, TM>(s_a[buf], s_out, s_dst[k], cnt, bcur, sbs, cg * NBW * 16, g,
                                         ln);
       }
+      unsigned long long t2 = SF_STAMP();
       // (3) park the prefetched rows in LDS for the next offset
       if (ABUF == 1) __syncthreads();
+      unsigned long long t3 = SF_STAMP();
       if (more) {
 #pragma unroll
         for (int m = 0; m < GI; ++m) {
           int idx = tid + m * NT, p = idx / CH, c = idx % CH;
-          if (idx < TM * CH && p < cnt_next)
+          if (EXACT || idx < TM * CH)
             *reinterpret_cast<f32x4 *>(
                 &s_a[ABUF == 2 ? (buf ^ 1) : 0][p * CIN + 4 * ATile<CIN>::pos(p, c)]) = greg[m];
         }
@@ -259,8 +298,19 @@ sparse_conv_f32_kernel(const float *__restrict__ feat, const int *__restrict__ n
 #pragma unroll
           for (int t = 0; t < T; ++t) bcur[i][t] = bnext[i][t];
       }
+      unsigned long long t4 = SF_STAMP();
       __syncthreads();
+      if (prof) {
+        unsigned long long t5 = __builtin_amdgcn_s_memtime();
+        pt[1] += t1 - t0;  // issue next gather + filter loads
+        pt[2] += t2 - t1;  // MFMA + tile update
+        pt[3] += t3 - t2;  // barrier 1
+        pt[4] += t4 - t3;  // wait loads, LDS store
+        pt[5] += t5 - t4;  // barrier 2
+        pt[7] += 1;
+      }
     }
+    unsigned long long tq = SF_STAMP();
 
     // ---- epilogue: folded BN, residual, ReLU; one coalesced write per output row ---------
     constexpr int OC = COUT / 4;
@@ -281,7 +331,16 @@ sparse_conv_f32_kernel(const float *__restrict__ feat, const int *__restrict__ n
       *reinterpret_cast<f32x4 *>(out + (size_t)row * COUT + 4 * c) = v;
     }
     __syncthreads();  // s_out / lists are reused by the next tile
+    if (prof) pt[6] += (unsigned long long)__builtin_amdgcn_s_memtime() - tq;  // epilogue
   }
+  if (prof && threadIdx.x == 0) {
+    unsigned long long tk1 = __builtin_amdgcn_s_memtime(), tr1 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < 8; ++i) atomicAdd(&prof[i], pt[i]);
+    atomicAdd(&prof[8], tk1 - tk0);   // cycles in kernel (this workgroup)
+    atomicAdd(&prof[9], tr1 - tr0);   // 100 MHz ticks in kernel
+    atomicAdd(&prof[10], 1ull);       // workgroups
+  }
+#undef SF_STAMP
 }
 
 // (K, cin, cout) -> fragment order [k][nb][t][lane] float4, element j = W[k][16t+4(lane>>4)+j][16nb+(lane&15)]
@@ -314,6 +373,8 @@ __global__ void pad_channels_kernel(const float *__restrict__ src, int cs, float
   }
 }
 
+unsigned long long *g_conv_prof = nullptr;  // diagnostic only, see sf_debug_conv_profile
+
 struct ConvArgs {
   const float *feat;
   const int *nbr;
@@ -339,7 +400,7 @@ int env_balance(int dflt) {
 
 template <int CIN, int COUT, int TM, int WAVES, int ABUF>
 int launch(const ConvArgs &a) {
-  constexpr size_t lds = (size_t)TM * (COUT + 4) * 4 + (size_t)ABUF * TM * CIN * 4 +
+  constexpr size_t lds = (size_t)(TM + 1) * (COUT + 4) * 4 + (size_t)ABUF * TM * CIN * 4 +
                          (size_t)kMaxK * TM * 5 + 256;
   static_assert(lds <= 160 * 1024, "tile does not fit LDS");
   // grid = what is resident at once (CUs x workgroups per CU), never more than the tiles
@@ -364,7 +425,7 @@ int launch(const ConvArgs &a) {
   hipLaunchKernelGGL((sparse_conv_f32_kernel<CIN, COUT, TM, WAVES, ABUF>), dim3(grid),
                      dim3(WAVES * 64), 0, a.st, a.feat, a.nbr, a.nbr_stride, a.K, a.k_first, a.wpk,
                      a.scale, a.shift, a.residual, a.relu, a.out, a.n_out_dev, a.n_out_bound,
-                     balance);
+                     balance, g_conv_prof);
   SF_CHECK_LAUNCH();
   return SF_OK;
 }
@@ -392,6 +453,11 @@ int launch_cfg(const ConvArgs &a) {
       case 6482: return launch<CIN, COUT, 64, 8, 2>(a);
       case 6441: return launch<CIN, COUT, 64, 4, 1>(a);
       case 6481: return launch<CIN, COUT, 64, 8, 1>(a);
+      case 8041: return launch<CIN, COUT, 80, 4, 1>(a);
+      case 8081: return launch<CIN, COUT, 80, 8, 1>(a);
+      case 8042:
+        if constexpr (CIN <= 64) return launch<CIN, COUT, 80, 4, 2>(a);
+        return launch<CIN, COUT, 80, 4, 1>(a);
       case 12881:
         return launch<CIN, COUT, 128, 8, 1>(a);
       case 12882:
@@ -483,4 +549,10 @@ extern "C" int sf_sparse_conv_f32(const float *features_in, int cin_padded, cons
   sf_set_error("unsupported cin_padded=%d (8, 16, 32, 64 or 128; see sf_conv_padded_cin)",
                cin_padded);
   return SF_ERR_BAD_ARG;
+}
+
+// Diagnostic hook (not part of the documented ABI surface used by callers): when set to a device
+// buffer of 16 uint64, every conv launch accumulates wave-0 cycle stamps per region into it.
+extern "C" __attribute__((visibility("default"))) void sf_debug_conv_profile(void *dev_buf16) {
+  g_conv_prof = (unsigned long long *)dev_buf16;
 }
