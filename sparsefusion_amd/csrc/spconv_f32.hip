@@ -16,6 +16,8 @@
 //   P*Cin*4 (gather) + N_out*Cout*4*(1+residual) (single write [+identity read]) + P*8 (indices)
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "sf_common.h"
 
 namespace {
@@ -44,9 +46,13 @@ struct ATile {
 // the wave's filter columns; the products are added into the LDS-resident output tile (plain
 // read-add-write: rows are unique per offset and offsets are separated by barriers; LDS float
 // atomics measured 2x slower end to end).
-template <int CIN, int NBW, int T, int NS, int OST, int TM>
+//   * the four destination rows of a lane are four consecutive bytes of the offset's list: one
+//     ds_read_b32 (list padding entries point at the spare row TM, so no bounds test);
+//   * the tile values to update are read BEFORE the MFMA chain so their LDS latency hides
+//     under it; A fragments are read one channel group ahead of the MFMAs that use them.
+template <int CIN, int NBW, int T, int NS, int OST>
 __device__ __forceinline__ void mma_blocks(const float *__restrict__ sa, float *__restrict__ s_out,
-                                           const unsigned char *__restrict__ dstk, int cnt,
+                                           const unsigned char *__restrict__ dstk,
                                            const f32x4 (&b)[NBW][T], const int (&sbs)[NS], int col0,
                                            int g, int ln) {
   constexpr int CH = CIN / 4;
@@ -54,28 +60,41 @@ __device__ __forceinline__ void mma_blocks(const float *__restrict__ sa, float *
   // still runs two independent MFMA chains; summed once at the end.
   constexpr int NA = (NS == 1 && T >= 2) ? 2 : NS;
   f32x4 acc[NA][NBW];
-  int dst[NS][4];
+  f32x4 a_cur[NS], a_nxt[NS];
+  unsigned d4[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    d4[s] = *reinterpret_cast<const unsigned *>(dstk + sbs[s] * 16 + g * 4);
+    const int p = sbs[s] * 16 + ln;
+    a_cur[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (CIN >= 16 || g < CH)
+      a_cur[s] = *reinterpret_cast<const f32x4 *>(&sa[p * CIN + 4 * ATile<CIN>::pos(p, g)]);
+  }
 #pragma unroll
   for (int s = 0; s < NA; ++s)
 #pragma unroll
     for (int i = 0; i < NBW; ++i) acc[s][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int off[NS][4];
+  float cur[NS][4][NBW];
 #pragma unroll
   for (int s = 0; s < NS; ++s)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      int q = sbs[s] * 16 + g * 4 + r;
-      int d = dstk[q < TM ? q : TM - 1];
-      dst[s][r] = (q < cnt) ? d : TM;  // padding rows land in the spare row TM of the tile
+      off[s][r] = (int)((d4[s] >> (8 * r)) & 255u) * OST + col0 + ln;
+#pragma unroll
+      for (int i = 0; i < NBW; ++i) cur[s][r][i] = s_out[off[s][r] + i * 16];
     }
+  __builtin_amdgcn_sched_barrier(0);  // keep these LDS reads ahead of the MFMA chain
 #pragma unroll
   for (int t = 0; t < T; ++t) {
-    f32x4 a4[NS];
+    if (t + 1 < T) {
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const int p = sbs[s] * 16 + ln;
-      a4[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (CIN >= 16 || g < CH)
-        a4[s] = *reinterpret_cast<const f32x4 *>(&sa[p * CIN + 4 * ATile<CIN>::pos(p, 4 * t + g)]);
+      for (int s = 0; s < NS; ++s) {
+        const int p = sbs[s] * 16 + ln;
+        a_nxt[s] = *reinterpret_cast<const f32x4 *>(
+            &sa[p * CIN + 4 * ATile<CIN>::pos(p, 4 * (t + 1) + g)]);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // issue the next group's reads before this group's MFMAs
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -84,34 +103,33 @@ __device__ __forceinline__ void mma_blocks(const float *__restrict__ sa, float *
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
           const int a = (NS == 1 && NA == 2) ? (t & 1) : s;
-          acc[a][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s][j], b[i][t][j], acc[a][i], 0, 0, 0);
+          acc[a][i] =
+              __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s][j], b[i][t][j], acc[a][i], 0, 0, 0);
         }
+    if (t + 1 < T) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) a_cur[s] = a_nxt[s];
+    }
   }
   if (NS == 1 && NA == 2) {
 #pragma unroll
     for (int i = 0; i < NBW; ++i) acc[0][i] += acc[1][i];
   }
-  float cur[NS][4][NBW];
 #pragma unroll
   for (int s = 0; s < NS; ++s)
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int i = 0; i < NBW; ++i) cur[s][r][i] = s_out[dst[s][r] * OST + col0 + i * 16 + ln];
-#pragma unroll
-  for (int s = 0; s < NS; ++s)
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int i = 0; i < NBW; ++i)
-        s_out[dst[s][r] * OST + col0 + i * 16 + ln] = cur[s][r][i] + acc[s][i][r];
+      for (int i = 0; i < NBW; ++i) s_out[off[s][r] + i * 16] = cur[s][r][i] + acc[s][i][r];
 }
 
-// TM    maximum output rows per tile (64 or 128); the kernel sizes its tiles at run time so
-//       that every workgroup of the grid gets the same number of tiles (no tail round)
+// TM    output rows a tile can hold (the LDS-resident fp32 tile); the kernel sizes its tiles at
+//       run time (<= TM) so that every workgroup of the grid gets the same number of tiles
+// AM    rows of the gathered-input tile; an offset with more than AM pairs in the tile is
+//       processed in chunks of AM (so TM is bounded by the output tile only)
 // WAVES wavefronts per workgroup (4 or 8)
-// ABUF  LDS buffers for the gathered rows (2: one barrier per offset, 1: two barriers, less LDS)
-template <int CIN, int COUT, int TM, int WAVES, int ABUF>
+// ABUF  LDS buffers for the gathered rows (2: one barrier per phase, 1: two barriers, less LDS)
+template <int CIN, int COUT, int TM, int AM, int WAVES, int ABUF>
 __global__ void __launch_bounds__(WAVES * 64)
 sparse_conv_f32_kernel(const float *__restrict__ feat, const int *__restrict__ nbr, int nbr_stride,
                        int K, int k_first, const float *__restrict__ wpk,
@@ -128,17 +146,20 @@ sparse_conv_f32_kernel(const float *__restrict__ feat, const int *__restrict__ n
   constexpr int NBW = NB / CG;                 // N blocks per wave
   constexpr int RG = WAVES / CG;               // wave groups along compact rows
   constexpr int OST = COUT + 4;                // padded output-tile row stride (floats)
-  constexpr int GI = (TM * CH + NT - 1) / NT;  // gather items per thread
+  constexpr int TMP = (TM + 15) & ~15;         // list length: padded to whole 16-row blocks
+  constexpr int GI = (AM * CH + NT - 1) / NT;  // gather items per thread
   constexpr int HALVES = (TM + 63) / 64;
-  constexpr bool EXACT = (TM * CH) % NT == 0;  // every thread owns GI whole gather items
+  constexpr bool EXACT = (AM * CH) % NT == 0;  // every thread owns GI whole gather items
   constexpr int KPW = (kMaxK + WAVES - 1) / WAVES;  // offsets compacted per wave
+  constexpr int NCH = (TM + AM - 1) / AM;           // chunks per offset at most
+  static_assert(TM <= 255 && AM % 16 == 0 && TM % 4 == 0, "tile shape");
 
   __shared__ __attribute__((aligned(16))) float s_out[(TM + 1) * OST];  // + spare row
-  __shared__ __attribute__((aligned(16))) float s_a[ABUF][TM * CIN];
-  __shared__ int s_src[kMaxK][TM];
-  __shared__ unsigned char s_dst[kMaxK][TM];
+  __shared__ __attribute__((aligned(16))) float s_a[ABUF][AM * CIN];
+  __shared__ int s_src[kMaxK][TMP];
+  __shared__ __attribute__((aligned(4))) unsigned char s_dst[kMaxK][TMP];
   __shared__ int s_cnt[kMaxK];
-  __shared__ int s_order[kMaxK + 1];
+  __shared__ int s_order[kMaxK * NCH + 1];  // phase list: k | (first pair of the chunk << 8)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cg = wave % CG, rg = wave / CG;
@@ -146,8 +167,8 @@ sparse_conv_f32_kernel(const float *__restrict__ feat, const int *__restrict__ n
   const int n_out = load_n(n_out_dev, n_out_bound);
   const f32x4 *__restrict__ wp4 = reinterpret_cast<const f32x4 *>(wpk);
 
-  // tile height: TM rows, or (SF_CONV_BALANCE=1) the largest height <= TM that gives every
-  // workgroup of the grid the same number of tiles
+  // tile height: TM rows, or (balance) the largest height <= TM that gives every workgroup of
+  // the grid the same number of tiles
   const int G = gridDim.x;
   int tm = TM;
   if (balance) {
@@ -198,106 +219,108 @@ sparse_conv_f32_kernel(const float *__restrict__ feat, const int *__restrict__ n
           }
           base += __popcll(m);
         }
+        // padding entries of the last 16-row block land in the spare row TM of the tile
+        if (lane < ((16 - base) & 15)) s_dst[k][base + lane] = (unsigned char)TM;
         if (lane == 0) s_cnt[k] = base;
       }
     }
     for (int i = tid; i < TM * OST; i += NT) s_out[i] = 0.0f;
     __syncthreads();
-    if (tid == 0) {  // visit order: k_first (SubM centre) then ascending, empty offsets skipped
-      int no = 0;
-      if (k_first >= 0 && k_first < K && s_cnt[k_first] > 0) s_order[no++] = k_first;
-      for (int k = 0; k < K; ++k)
-        if (k != k_first && s_cnt[k] > 0) s_order[no++] = k;
-      s_order[kMaxK] = no;
+    if (wave == 0) {
+      // phase list: k_first (SubM centre) first, then k ascending; an offset with c pairs takes
+      // ceil(c / AM) phases; empty offsets take none.  Lane k places offset k's phases.
+      const int c = (lane < K) ? s_cnt[lane] : 0;
+      const int nch = (c + AM - 1) / AM;
+      const int incl = sf_wave_incl_scan(nch);
+      const int total = __shfl(incl, 63, 64);
+      int pre = incl - nch;
+      if (k_first >= 0 && k_first < K) {
+        const int cf = __shfl(nch, k_first, 64);
+        pre = (lane < k_first) ? pre + cf : (lane == k_first ? 0 : pre);
+      }
+      for (int j = 0; j < nch; ++j) s_order[pre + j] = lane | ((j * AM) << 8);
+      if (lane == 0) s_order[kMaxK * NCH] = total;
     }
     __syncthreads();
-    const int n_order = s_order[kMaxK];
+    const int n_order = s_order[kMaxK * NCH];
 
-    f32x4 greg[GI];
+    // ---- phase pipeline ------------------------------------------------------------------
+    // While phase e multiplies the rows parked in LDS, the rows of phase e+1 are in flight
+    // into register set (e+1)&1 (issued one phase ago) and the loads of phase e+2 are issued
+    // into set e&1: a random HBM row takes longer than one phase to arrive.  Phases past the
+    // end re-read one cached row (count 0) so that every phase is the same straight-line code
+    // and the compiler's load counters stay exact.
+    f32x4 greg[2][GI];
     f32x4 bcur[NBW][T], bnext[NBW][T];
-    if (n_order > 0) {
-      const int k = s_order[0], cnt = s_cnt[k];
+    auto phase_at = [&](int e, int &k, int &st, int &cnt) {
+      const int ec = e < 0 ? 0 : (e < n_order ? e : n_order - 1);
+      const int ent = s_order[ec];
+      k = ent & 255;
+      st = ent >> 8;
+      int c = s_cnt[k] - st;
+      c = c < AM ? c : AM;
+      cnt = (e == ec) ? c : 0;
+    };
+    auto load_filters = [&](f32x4(&bf)[NBW][T], int k) {
 #pragma unroll
       for (int i = 0; i < NBW; ++i)
 #pragma unroll
         for (int t = 0; t < T; ++t)
-          bcur[i][t] = wp4[(((size_t)k * NB + (cg * NBW + i)) * T + t) * 64 + lane];
+          bf[i][t] = wp4[(((size_t)k * NB + (cg * NBW + i)) * T + t) * 64 + lane];
+    };
+    auto gather_issue = [&](f32x4(&gr)[GI], int k, int st, int cnt) {
+#pragma unroll
+      for (int m = 0; m < GI; ++m) {
+        // rows past cnt are never consumed: they re-read list entry 0 (one cache line)
+        int idx = tid + m * NT, p = idx / CH, c = idx % CH;
+        if (EXACT || idx < AM * CH)
+          gr[m] = *reinterpret_cast<const f32x4 *>(
+              feat + (size_t)s_src[k][st + (p < cnt ? p : 0)] * CIN + 4 * c);
+      }
+    };
+    auto gather_park = [&](const f32x4(&gr)[GI], float *sa) {
 #pragma unroll
       for (int m = 0; m < GI; ++m) {
         int idx = tid + m * NT, p = idx / CH, c = idx % CH;
-        if (EXACT || idx < TM * CH)
-          greg[m] = *reinterpret_cast<const f32x4 *>(
-              feat + (size_t)s_src[k][p < cnt ? p : 0] * CIN + 4 * c);
+        if (EXACT || idx < AM * CH)
+          *reinterpret_cast<f32x4 *>(&sa[p * CIN + 4 * ATile<CIN>::pos(p, c)]) = gr[m];
       }
-#pragma unroll
-      for (int m = 0; m < GI; ++m) {
-        int idx = tid + m * NT, p = idx / CH, c = idx % CH;
-        if (EXACT || idx < TM * CH)
-          *reinterpret_cast<f32x4 *>(&s_a[0][p * CIN + 4 * ATile<CIN>::pos(p, c)]) = greg[m];
-      }
-    }
-    __syncthreads();
-    {
-      unsigned long long te = SF_STAMP();
-      pt[0] += te - ts;  // setup + first gather
-    }
-
-    for (int kk = 0; kk < n_order; ++kk) {
+    };
+    // one phase; PAR = parity of kk = register set that receives the loads of phase kk+2
+    auto phase = [&](int kk, auto PAR) {
+      constexpr int par = decltype(PAR)::value;
       unsigned long long t0 = SF_STAMP();
-      const int k = s_order[kk], cnt = s_cnt[k];
-      const int buf = (ABUF == 2) ? (kk & 1) : 0;
-      const bool more = kk + 1 < n_order;
-      // (1) issue the next offset's gather and filter loads (they land while we compute)
-      int cnt_next = 0;
-      if (more) {
-        const int k_next = s_order[kk + 1];
-        cnt_next = s_cnt[k_next];
-#pragma unroll
-        for (int m = 0; m < GI; ++m) {
-          // rows past cnt_next are never consumed: they re-read list entry 0 (one cache line)
-          // so that the loads and LDS stores stay straight-line code
-          int idx = tid + m * NT, p = idx / CH, c = idx % CH;
-          if (EXACT || idx < TM * CH)
-            greg[m] = *reinterpret_cast<const f32x4 *>(
-                feat + (size_t)s_src[k_next][p < cnt_next ? p : 0] * CIN + 4 * c);
-        }
-#pragma unroll
-        for (int i = 0; i < NBW; ++i)
-#pragma unroll
-          for (int t = 0; t < T; ++t)
-            bnext[i][t] = wp4[(((size_t)k_next * NB + (cg * NBW + i)) * T + t) * 64 + lane];
-      }
+      int k, st, cnt, k1, st1, cnt1, k2, st2, cnt2;
+      phase_at(kk, k, st, cnt);
+      phase_at(kk + 1, k1, st1, cnt1);
+      phase_at(kk + 2, k2, st2, cnt2);
+      float *sa_cur = s_a[ABUF == 2 ? par : 0];
+      float *sa_nxt = s_a[ABUF == 2 ? (par ^ 1) : 0];
+      // (1) issue: filters of phase kk+1, rows of phase kk+2
+      load_filters(bnext, k1);
+      gather_issue(greg[par], k2, st2, cnt2);
       unsigned long long t1 = SF_STAMP();
-      // (2) this offset: MFMA over the compacted rows, products added into the LDS tile
+      // (2) this phase: MFMA over the compacted rows, products added into the LDS tile
       const int nsb = (cnt + 15) >> 4;
+      const unsigned char *dstk = &s_dst[k][st];
       int sb = rg;
       for (; sb + RG < nsb; sb += 2 * RG) {
         const int sbs[2] = {sb, sb + RG};
-        mma_blocks<CIN, NBW, T, 2, OST, TM>(s_a[buf], s_out, s_dst[k], cnt, bcur, sbs, cg * NBW * 16, g,
-                                        ln);
+        mma_blocks<CIN, NBW, T, 2, OST>(sa_cur, s_out, dstk, bcur, sbs, cg * NBW * 16, g, ln);
       }
       if (sb < nsb) {
         const int sbs[1] = {sb};
-        mma_blocks<CIN, NBW, T, 1, OST, TM>(s_a[buf], s_out, s_dst[k], cnt, bcur, sbs, cg * NBW * 16, g,
-                                        ln);
+        mma_blocks<CIN, NBW, T, 1, OST>(sa_cur, s_out, dstk, bcur, sbs, cg * NBW * 16, g, ln);
       }
       unsigned long long t2 = SF_STAMP();
-      // (3) park the prefetched rows in LDS for the next offset
+      // (3) park the rows of phase kk+1 (issued one phase ago) in LDS
       if (ABUF == 1) __syncthreads();
       unsigned long long t3 = SF_STAMP();
-      if (more) {
+      gather_park(greg[par ^ 1], sa_nxt);
 #pragma unroll
-        for (int m = 0; m < GI; ++m) {
-          int idx = tid + m * NT, p = idx / CH, c = idx % CH;
-          if (EXACT || idx < TM * CH)
-            *reinterpret_cast<f32x4 *>(
-                &s_a[ABUF == 2 ? (buf ^ 1) : 0][p * CIN + 4 * ATile<CIN>::pos(p, c)]) = greg[m];
-        }
+      for (int i = 0; i < NBW; ++i)
 #pragma unroll
-        for (int i = 0; i < NBW; ++i)
-#pragma unroll
-          for (int t = 0; t < T; ++t) bcur[i][t] = bnext[i][t];
-      }
+        for (int t = 0; t < T; ++t) bcur[i][t] = bnext[i][t];
       unsigned long long t4 = SF_STAMP();
       __syncthreads();
       if (prof) {
@@ -308,6 +331,25 @@ sparse_conv_f32_kernel(const float *__restrict__ feat, const int *__restrict__ n
         pt[4] += t4 - t3;  // wait loads, LDS store
         pt[5] += t5 - t4;  // barrier 2
         pt[7] += 1;
+      }
+    };
+    {
+      unsigned long long te = SF_STAMP();
+      pt[0] += te - ts;  // setup
+    }
+    // The pipeline is primed by the loop itself: phases -2 and -1 have no rows to multiply,
+    // they only issue the loads of phases 0 and 1.  One loop body, one back edge, nothing
+    // carried into the loop: the compiler's outstanding-load counts stay exact.
+    if (n_order > 0) {
+#pragma unroll
+      for (int m = 0; m < GI; ++m) greg[0][m] = greg[1][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < NBW; ++i)
+#pragma unroll
+        for (int t = 0; t < T; ++t) bcur[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int kk = -2; kk < n_order; kk += 2) {
+        phase(kk, std::integral_constant<int, 0>{});
+        phase(kk + 1, std::integral_constant<int, 1>{});
       }
     }
     unsigned long long tq = SF_STAMP();
@@ -398,10 +440,12 @@ int env_balance(int dflt) {
   return v < 0 ? dflt : (v & 1);
 }
 
-template <int CIN, int COUT, int TM, int WAVES, int ABUF>
-int launch(const ConvArgs &a) {
-  constexpr size_t lds = (size_t)(TM + 1) * (COUT + 4) * 4 + (size_t)ABUF * TM * CIN * 4 +
-                         (size_t)kMaxK * TM * 5 + 256;
+template <int CIN, int COUT, int TM, int AM, int WAVES, int ABUF>
+int launch(const ConvArgs &a, int balance_default) {
+  constexpr int TMP = (TM + 15) & ~15;
+  constexpr size_t lds = (size_t)(TM + 1) * (COUT + 4) * 4 + (size_t)ABUF * AM * CIN * 4 +
+                         (size_t)kMaxK * TMP * 5 + (size_t)kMaxK * (((TM + AM - 1) / AM) + 1) * 4 +
+                         64;
   static_assert(lds <= 160 * 1024, "tile does not fit LDS");
   // grid = what is resident at once (CUs x workgroups per CU), never more than the tiles
   static int slots = 0;
@@ -411,18 +455,19 @@ int launch(const ConvArgs &a) {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
       cus = prop.multiProcessorCount;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &per_cu, sparse_conv_f32_kernel<CIN, COUT, TM, WAVES, ABUF>, WAVES * 64, 0) != hipSuccess ||
+            &per_cu, sparse_conv_f32_kernel<CIN, COUT, TM, AM, WAVES, ABUF>, WAVES * 64, 0) !=
+            hipSuccess ||
         per_cu < 1)
       per_cu = 1;
     int by_lds = (int)((160 * 1024) / lds);
     if (per_cu > by_lds) per_cu = by_lds < 1 ? 1 : by_lds;
     slots = cus * per_cu;
   }
-  const int balance = env_balance((CIN >= 128 && COUT >= 128) ? 1 : 0);
+  const int balance = env_balance(balance_default);
   int tiles = sf_div_up(a.n_out_bound, balance ? 32 : TM);
   int cap = balance ? slots : 4096;
   int grid = tiles < cap ? tiles : cap;
-  hipLaunchKernelGGL((sparse_conv_f32_kernel<CIN, COUT, TM, WAVES, ABUF>), dim3(grid),
+  hipLaunchKernelGGL((sparse_conv_f32_kernel<CIN, COUT, TM, AM, WAVES, ABUF>), dim3(grid),
                      dim3(WAVES * 64), 0, a.st, a.feat, a.nbr, a.nbr_stride, a.K, a.k_first, a.wpk,
                      a.scale, a.shift, a.residual, a.relu, a.out, a.n_out_dev, a.n_out_bound,
                      balance, g_conv_prof);
@@ -430,46 +475,61 @@ int launch(const ConvArgs &a) {
   return SF_OK;
 }
 
-// Experiment hook: SF_CONV_CFG="tm,waves,abuf" overrides the per-shape default (read once).
-int env_cfg() {
-  static int cfg = -2;
+// Experiment hook: SF_CONV_CFG="tm,am,waves,abuf" overrides the per-shape default (read once).
+long env_cfg() {
+  static long cfg = -2;
   if (cfg == -2) {
     cfg = -1;
     const char *e = getenv("SF_CONV_CFG");
-    int tm, w, ab;
-    if (e && sscanf(e, "%d,%d,%d", &tm, &w, &ab) == 3) cfg = tm * 100 + w * 10 + ab;
+    int tm, am, w, ab;
+    if (e && sscanf(e, "%d,%d,%d,%d", &tm, &am, &w, &ab) == 4)
+      cfg = ((tm * 1000L + am) * 10 + w) * 10 + ab;
   }
   return cfg;
 }
 
+#define SF_CFG(tm, am, w, ab) ((((tm) * 1000L + (am)) * 10 + (w)) * 10 + (ab))
+#define SF_CASE(tm, am, w, ab) \
+  case SF_CFG(tm, am, w, ab):  \
+    return launch<CIN, COUT, tm, am, w, ab>(a, bal)
+
 template <int CIN, int COUT>
 int launch_cfg(const ConvArgs &a) {
-  constexpr bool big = (CIN >= 32 && COUT >= 32);  // shapes that get the tuning variants
-  int cfg = env_cfg();
-  if (cfg < 0 || !big) cfg = (COUT >= 128) ? 6481 : (CIN >= 64 ? 6441 : 6442);  // measured best
+  // shapes of the SparseEncoder's wide stages get the tuning variants
+  constexpr bool big = CIN >= 32 && (COUT == CIN || COUT == 2 * CIN);
   if constexpr (big) {
-    switch (cfg) {
-      case 6442: return launch<CIN, COUT, 64, 4, 2>(a);
-      case 6482: return launch<CIN, COUT, 64, 8, 2>(a);
-      case 6441: return launch<CIN, COUT, 64, 4, 1>(a);
-      case 6481: return launch<CIN, COUT, 64, 8, 1>(a);
-      case 8041: return launch<CIN, COUT, 80, 4, 1>(a);
-      case 8081: return launch<CIN, COUT, 80, 8, 1>(a);
-      case 8042:
-        if constexpr (CIN <= 64) return launch<CIN, COUT, 80, 4, 2>(a);
-        return launch<CIN, COUT, 80, 4, 1>(a);
-      case 12881:
-        return launch<CIN, COUT, 128, 8, 1>(a);
-      case 12882:
-        if constexpr (CIN <= 64 && COUT <= 64) return launch<CIN, COUT, 128, 8, 2>(a);
-        return launch<CIN, COUT, 128, 8, 1>(a);
+    long cfg = env_cfg();
+    int bal = 0;
+    if (cfg < 0) {  // measured best per shape (tools/sweep_conv.sh)
+      bal = 1;
+      if (CIN >= 128)
+        cfg = SF_CFG(96, 64, 8, 1);
+      else if (CIN >= 64)
+        cfg = SF_CFG(88, 64, 4, 1);
+      else
+        cfg = SF_CFG(80, 64, 4, 1);
     }
-    sf_set_error("unknown SF_CONV_CFG %d", cfg);
+    switch (cfg) {
+      SF_CASE(64, 64, 4, 2);
+      SF_CASE(64, 64, 4, 1);
+      SF_CASE(64, 64, 8, 1);
+      SF_CASE(64, 48, 4, 1);
+      SF_CASE(64, 48, 8, 1);
+      SF_CASE(68, 64, 8, 1);
+      SF_CASE(80, 48, 8, 1);
+      SF_CASE(80, 64, 4, 1);
+      SF_CASE(88, 64, 4, 1);
+      SF_CASE(96, 48, 4, 1);
+      SF_CASE(96, 64, 8, 1);
+      SF_CASE(128, 64, 8, 1);
+    }
+    sf_set_error("unknown SF_CONV_CFG %ld", cfg);
     return SF_ERR_BAD_ARG;
   } else {
-    return launch<CIN, COUT, 64, 4, 2>(a);
+    return launch<CIN, COUT, 64, 64, 4, 2>(a, 0);
   }
 }
+#undef SF_CASE
 
 template <int CIN>
 int dispatch_cout(int cout, const ConvArgs &a) {
