@@ -39,7 +39,7 @@ PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA dense peak
 
 
-def build_backbone(workload, dev, batch, max_points):
+def build_backbone(workload, dev, batch, max_points, overlap=True):
     cfg = configs.NUSC if workload == 'nusc' else configs.WAYMO
     ecfg = dict(cfg['pts_middle_encoder'])
     ecfg.pop('type')
@@ -49,7 +49,8 @@ def build_backbone(workload, dev, batch, max_points):
     enc = SparseEncoder(**ecfg)
     enc.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
     enc = enc.to(dev).eval()
-    bb = LidarBackbone(cfg['pts_voxel_layer'], enc, dev, max_points, batch_size=batch)
+    bb = LidarBackbone(cfg['pts_voxel_layer'], enc, dev, max_points, batch_size=batch,
+                       overlap=overlap)
     return cfg, ecfg, sd, enc, bb
 
 
@@ -147,6 +148,8 @@ def main():
     ap.add_argument('--streams', type=int, default=1,
                     help='frames in flight per GPU (each on its own HIP stream and workspace)')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-overlap', action='store_true',
+                    help='coordinate phase on the main stream instead of a forked one')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--detail', default='', help='write per-layer timing/roofline JSON here')
     args = ap.parse_args()
@@ -168,10 +171,11 @@ def main():
     ids = sharding.frames_for_rank(rank, world, world * args.frames * B)
     host_frames = [gen(i) for i in ids]
     max_pts = max(p.shape[0] for p in host_frames)
-    cfg, ecfg, sd, enc, bb = build_backbone(args.workload, dev, B, max_pts)
+    cfg, ecfg, sd, enc, bb = build_backbone(args.workload, dev, B, max_pts, not args.no_overlap)
     # frames in flight: independent frames on independent streams fill each other's tail rounds
     # and barrier bubbles; every stream has its own workspace, weights are shared
-    lanes = [bb] + [LidarBackbone(cfg['pts_voxel_layer'], enc, dev, max_pts, batch_size=B)
+    lanes = [bb] + [LidarBackbone(cfg['pts_voxel_layer'], enc, dev, max_pts, batch_size=B,
+                                  overlap=not args.no_overlap)
                     for _ in range(args.streams - 1)]
     streams = [torch.cuda.Stream(device=dev) for _ in lanes]
     frames = [[torch.from_numpy(host_frames[f * B + b]).to(dev) for b in range(B)]

@@ -385,6 +385,375 @@ sparse_conv_f32_kernel(const float *__restrict__ feat, const int *__restrict__ n
 #undef SF_STAMP
 }
 
+// ---------------------------------------------------------------------------------------------
+// "Wide" variant: Cout/16 is a multiple of the wave count, so every wave owns its output columns
+// for ALL compacted rows of a phase.  Nobody else touches a wave's columns of the LDS tile, a
+// phase needs ONE barrier (the gathered rows are double buffered), and the phase body is
+// straight-line code specialised on the number of 16-row blocks.  The bookkeeping of the pipeline
+// (list reads, address arithmetic, loads for later phases, parking gathered rows, the
+// read-add-write of finished blocks) is spread over the MFMA stream with sched_group_barrier, so
+// it issues in the shadow of the matrix pipe instead of in front of it.
+template <int CIN, int COUT, int TM, int AM, int WAVES>
+struct WideShape {
+  static constexpr int NT = WAVES * 64;
+  static constexpr int T = CIN / 16;    // 16-channel groups
+  static constexpr int CH = CIN / 4;    // 16-byte chunks per row
+  static constexpr int NB = COUT / 16;  // N blocks
+  static constexpr int NBW = NB / WAVES;
+  static constexpr int OST = COUT + 4;
+  static constexpr int TMP = (TM + 15) & ~15;
+  static constexpr int GI = AM * CH / NT;
+  static constexpr int HALVES = (TM + 63) / 64;
+  static constexpr int KPW = (kMaxK + WAVES - 1) / WAVES;
+  static constexpr int NCH = (TM + AM - 1) / AM;
+  static constexpr int NMETA = kMaxK * NCH + 6;
+  static constexpr int MAXSB = AM / 16;
+  static constexpr int cin = CIN;
+  static_assert(NB % WAVES == 0 && (AM * CH) % NT == 0 && T >= 2 && AM % 16 == 0 && AM <= 64 &&
+                    TM <= 255 && TM % 4 == 0,
+                "shape not supported by the wide kernel");
+};
+
+// phase descriptor: offset k | first pair of the chunk << 8 | pairs in the chunk << 16
+#define SF_META_K(m) ((m) & 31)
+#define SF_META_ST(m) (((m) >> 8) & 255)
+#define SF_META_CNT(m) (((m) >> 16) & 255)
+
+template <class S, int NSB, int PAR>
+__device__ __forceinline__ void wide_phase(const float *__restrict__ feat,
+                                           const f32x4 *__restrict__ wp4, float *__restrict__ s_out,
+                                           float *__restrict__ sa_cur, float *__restrict__ sa_nxt,
+                                           const int *__restrict__ s_src,
+                                           const unsigned char *__restrict__ s_dst,
+                                           const int *__restrict__ meta_i, int tid, int lane,
+                                           int wave, int &m0, int &m1, f32x4 (&greg)[2][S::GI],
+                                           f32x4 (&bf)[2][S::NBW][S::T]) {
+  constexpr int T = S::T, NBW = S::NBW, GI = S::GI, CH = S::CH, OST = S::OST, TMP = S::TMP;
+  constexpr int NT = S::NT, NB = S::NB, CIN = S::cin;
+  constexpr int NG = (NSB + 1) / 2;  // groups of two row blocks (the last may hold one)
+  const int g = lane >> 4, ln = lane & 15, col0 = wave * NBW * 16;
+  const int k0 = SF_META_K(m0), st0 = SF_META_ST(m0), k1 = SF_META_K(m1);
+  const unsigned char *dstk = s_dst + k0 * TMP + st0;
+
+  int m2v = 0, m2 = 0;
+  int srow[GI];
+  unsigned d4[NG > 0 ? NG : 1][2];
+  f32x4 a_cur[2], a_nxt[2];
+  f32x4 acc[2][NBW], accp[2][NBW];
+  int off[2][4], offp[2][4];
+  float cur[2][4][NBW], curp[2][4][NBW];
+
+  // ---- pipeline bookkeeping, one small piece per MFMA unit -----------------------------
+  auto side = [&](int s) {
+    if (s == 0) {  // descriptor of phase i+2; filter fragments of phase i+1
+      m2v = meta_i[2];
+#pragma unroll
+      for (int i = 0; i < NBW; ++i)
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+          bf[PAR ^ 1][i][t] = wp4[(((size_t)k1 * NB + (wave * NBW + i)) * T + t) * 64 + lane];
+    } else if (s == 1) {  // input rows of phase i+2 (past the count: entry 0, one cached row)
+      m2 = __builtin_amdgcn_readfirstlane(m2v);
+      const int k2 = SF_META_K(m2), st2 = SF_META_ST(m2), cnt2 = SF_META_CNT(m2);
+#pragma unroll
+      for (int m = 0; m < GI; ++m) {
+        const int p = (tid + m * NT) / CH;
+        srow[m] = s_src[k2 * TMP + st2 + (p < cnt2 ? p : 0)];
+      }
+    } else if (s == 2) {  // gather loads of phase i+2
+#pragma unroll
+      for (int m = 0; m < GI; ++m) {
+        const int c = (tid + m * NT) % CH;
+        greg[PAR][m] = *reinterpret_cast<const f32x4 *>(feat + (size_t)srow[m] * CIN + 4 * c);
+      }
+    } else if (s == 3) {  // park the rows of phase i+1 (issued one phase ago)
+#pragma unroll
+      for (int m = 0; m < GI; ++m) {
+        const int idx = tid + m * NT, p = idx / CH, c = idx % CH;
+        *reinterpret_cast<f32x4 *>(&sa_nxt[p * CIN + 4 * ATile<CIN>::pos(p, c)]) = greg[PAR ^ 1][m];
+      }
+    }
+  };
+  auto a_read = [&](f32x4(&a)[2], int gi, int t, int ns) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      if (s < ns) {
+        const int p = (2 * gi + s) * 16 + ln;
+        a[s] = *reinterpret_cast<const f32x4 *>(&sa_cur[p * CIN + 4 * ATile<CIN>::pos(p, 4 * t + g)]);
+      }
+  };
+  auto scatter_prev = [&](int ns) {
+    if (ns == 1) {  // a lone block ran as two chains (even / odd channel groups)
+#pragma unroll
+      for (int i = 0; i < NBW; ++i) accp[0][i] += accp[1][i];
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      if (s < ns) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int i = 0; i < NBW; ++i)
+            s_out[offp[s][r] + i * 16] = curp[s][r][i] + accp[s][i][r];
+      }
+  };
+
+  if (NG > 0) {
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        if (2 * gi + s < NSB)
+          d4[gi][s] = *reinterpret_cast<const unsigned *>(dstk + (2 * gi + s) * 16 + g * 4);
+    a_read(a_cur, 0, 0, NSB >= 2 ? 2 : 1);
+  }
+  int u = 0;
+#pragma unroll
+  for (int gi = 0; gi < NG; ++gi) {
+    const int ns = (2 * gi + 1 < NSB) ? 2 : 1;
+#pragma unroll
+    for (int t = 0; t < T; ++t, ++u) {
+      if (u < 4) side(u);
+      if (t == 0) {
+        if (gi > 0) scatter_prev(2);  // every group before the last holds two blocks
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+          for (int i = 0; i < NBW; ++i) acc[s][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (s < ns) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              off[s][r] = (int)((d4[gi][s] >> (8 * r)) & 255u) * OST + col0 + ln;
+#pragma unroll
+              for (int i = 0; i < NBW; ++i) cur[s][r][i] = s_out[off[s][r] + i * 16];
+            }
+          }
+        }
+      }
+      if (t + 1 < T)
+        a_read(a_nxt, gi, t + 1, ns);
+      else if (gi + 1 < NG)
+        a_read(a_nxt, gi + 1, 0, (2 * gi + 3 < NSB) ? 2 : 1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < NBW; ++i)
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+            if (s < ns) {
+              const int a = (ns == 2) ? s : (t & 1);
+              acc[a][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s][j], bf[PAR][i][t][j],
+                                                              acc[a][i], 0, 0, 0);
+            }
+      // one MFMA, then a few of everything else: the bookkeeping issues while the pipe is busy
+#pragma unroll
+      for (int q = 0; q < 4 * NBW * 2; ++q) {
+        if (q < 4 * NBW * ns) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x096, 6, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) a_cur[s] = a_nxt[s];
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int i = 0; i < NBW; ++i) accp[s][i] = acc[s][i];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        offp[s][r] = off[s][r];
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) curp[s][r][i] = cur[s][r][i];
+      }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+    if (s >= u) side(s);
+  if (NG > 0) scatter_prev((NSB & 1) ? 1 : 2);
+  m0 = m1;
+  m1 = m2;
+}
+
+template <int CIN, int COUT, int TM, int AM, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
+sparse_conv_f32_wide_kernel(const float *__restrict__ feat, const int *__restrict__ nbr,
+                            int nbr_stride, int K, int k_first, const float *__restrict__ wpk,
+                            const float *__restrict__ scale, const float *__restrict__ shift,
+                            const float *__restrict__ residual, int relu, float *__restrict__ out,
+                            const int *n_out_dev, int n_out_bound, int balance,
+                            unsigned long long *__restrict__ prof) {
+  using S = WideShape<CIN, COUT, TM, AM, WAVES>;
+  constexpr int NT = S::NT, T = S::T, NBW = S::NBW, OST = S::OST, TMP = S::TMP, GI = S::GI;
+  constexpr int HALVES = S::HALVES, KPW = S::KPW, NMETA = S::NMETA;
+
+  __shared__ __attribute__((aligned(16))) float s_out[(TM + 1) * OST];  // + spare row
+  __shared__ __attribute__((aligned(16))) float s_a[2][AM * CIN];
+  __shared__ int s_src[kMaxK * TMP];
+  __shared__ __attribute__((aligned(4))) unsigned char s_dst[kMaxK * TMP];
+  __shared__ int s_cnt[kMaxK];
+  __shared__ int s_meta[NMETA + 1];  // [NMETA] = number of phases
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n_out = load_n(n_out_dev, n_out_bound);
+  const f32x4 *__restrict__ wp4 = reinterpret_cast<const f32x4 *>(wpk);
+
+  const int G = gridDim.x;
+  int tm = TM;
+  if (balance) {
+    const int rounds = (n_out + G * TM - 1) / (G * TM);
+    tm = rounds > 0 ? (n_out + G * rounds - 1) / (G * rounds) : TM;
+    if (tm < 32) tm = 32;
+    if (tm > TM) tm = TM;
+  }
+  const int tiles = (n_out + tm - 1) / tm;
+  // diagnostic stamps (prof != NULL only in profiling runs): cycles per region, per tile
+  unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tk0 = 0, tr0 = 0;
+#define SF_STAMP() (prof ? (unsigned long long)__builtin_amdgcn_s_memtime() : 0ull)
+  if (prof) {
+    tk0 = __builtin_amdgcn_s_memtime();
+    tr0 = __builtin_amdgcn_s_memrealtime();
+  }
+
+  for (int tile = blockIdx.x; tile < tiles; tile += G) {
+    unsigned long long ts = SF_STAMP();
+    const int row0 = tile * tm;
+    const int row_end = (row0 + tm < n_out) ? row0 + tm : n_out;
+    // ---- setup: compact the tile's pairs per offset, clear the output tile --------------
+    int nv[KPW][HALVES];
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+      const int k = wave + i * WAVES;
+#pragma unroll
+      for (int h = 0; h < HALVES; ++h) {
+        int o = row0 + h * 64 + lane;
+        nv[i][h] = (k < K && o < row_end) ? nbr[(size_t)k * nbr_stride + o] : -1;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+      const int k = wave + i * WAVES;
+      if (k < K) {
+        int base = 0;
+#pragma unroll
+        for (int h = 0; h < HALVES; ++h) {
+          int v = nv[i][h];
+          unsigned long long m = __ballot(v >= 0);
+          int pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                     __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+          if (v >= 0) {
+            s_src[k * TMP + pos] = v;
+            s_dst[k * TMP + pos] = (unsigned char)(h * 64 + lane);
+          }
+          base += __popcll(m);
+        }
+        // padding entries of the last 16-row block land in the spare row TM of the tile
+        if (lane < ((16 - base) & 15)) s_dst[k * TMP + base + lane] = (unsigned char)TM;
+        if (lane == 0) s_cnt[k] = base;
+      }
+    }
+    for (int i = tid; i < TM * OST; i += NT) s_out[i] = 0.0f;
+    __syncthreads();
+    if (wave == 0) {
+      // phase list: k_first (SubM centre) first, then k ascending; an offset with c pairs takes
+      // ceil(c / AM) phases; empty offsets take none.  Lane k places offset k's phases.  Two
+      // empty phases in front prime the pipeline, four behind drain it.
+      const int c = (lane < K) ? s_cnt[lane] : 0;
+      const int nch = (c + AM - 1) / AM;
+      const int incl = sf_wave_incl_scan(nch);
+      const int total = __shfl(incl, 63, 64);
+      int pre = incl - nch;
+      if (k_first >= 0 && k_first < K) {
+        const int cf = __shfl(nch, k_first, 64);
+        pre = (lane < k_first) ? pre + cf : (lane == k_first ? 0 : pre);
+      }
+      for (int j = 0; j < nch; ++j) {
+        const int left = c - j * AM;
+        s_meta[2 + pre + j] = lane | ((j * AM) << 8) | ((left < AM ? left : AM) << 16);
+      }
+      const unsigned long long any = __ballot(nch > 0);
+      const int kd = any ? (int)__ffsll((long long)any) - 1 : 0;  // an offset that has pairs
+      if (lane < 2) s_meta[lane] = kd;
+      if (lane >= 2 && lane < 6) s_meta[total + lane] = kd;
+      if (lane == 0) s_meta[NMETA] = total;
+    }
+    __syncthreads();
+    const int n_phase = s_meta[NMETA];
+    unsigned long long tp = SF_STAMP();
+    pt[0] += tp - ts;  // setup
+    pt[7] += n_phase;
+
+    if (n_phase > 0) {
+      f32x4 greg[2][GI];
+      f32x4 bf[2][NBW][T];
+#pragma unroll
+      for (int m = 0; m < GI; ++m) greg[0][m] = greg[1][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < NBW; ++i)
+#pragma unroll
+        for (int t = 0; t < T; ++t) bf[0][i][t] = bf[1][i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      int m0 = __builtin_amdgcn_readfirstlane(s_meta[0]);
+      int m1 = __builtin_amdgcn_readfirstlane(s_meta[1]);
+      const int n_steps = (n_phase + 3) & ~1;  // two priming phases in front, rounded up to even
+#define SF_WIDE_PHASE(NSB, PAR, I)                                                              \
+  wide_phase<S, NSB, PAR>(feat, wp4, s_out, s_a[PAR], s_a[PAR ^ 1], s_src, s_dst, &s_meta[I], tid, \
+                          lane, wave, m0, m1, greg, bf)
+#define SF_WIDE_DISPATCH(PAR, I)                                   \
+  switch ((SF_META_CNT(m0) + 15) >> 4) {                           \
+    case 0: SF_WIDE_PHASE(0, PAR, I); break;                       \
+    case 1: SF_WIDE_PHASE(1, PAR, I); break;                       \
+    case 2: SF_WIDE_PHASE(2, PAR, I); break;                       \
+    case 3: SF_WIDE_PHASE(3, PAR, I); break;                       \
+    default:                                                       \
+      if constexpr (S::MAXSB >= 4) SF_WIDE_PHASE(4, PAR, I);       \
+      break;                                                       \
+  }
+      for (int i = 0; i < n_steps; i += 2) {
+        SF_WIDE_DISPATCH(0, i)
+        __syncthreads();
+        SF_WIDE_DISPATCH(1, i + 1)
+        __syncthreads();
+      }
+#undef SF_WIDE_DISPATCH
+#undef SF_WIDE_PHASE
+    }
+
+    unsigned long long tq = SF_STAMP();
+    pt[2] += tq - tp;  // all phases of the tile (incl. the two priming ones)
+    // ---- epilogue: folded BN, residual, ReLU; one coalesced write per output row ---------
+    constexpr int OC = COUT / 4;
+    for (int idx = tid; idx < TM * OC; idx += NT) {
+      int r = idx / OC, c = idx % OC, row = row0 + r;
+      if (row >= row_end) continue;
+      f32x4 v = *reinterpret_cast<const f32x4 *>(&s_out[r * OST + 4 * c]);
+      if (scale) {
+        f32x4 sc = *reinterpret_cast<const f32x4 *>(scale + 4 * c);
+        f32x4 sh = *reinterpret_cast<const f32x4 *>(shift + 4 * c);
+        v = v * sc + sh;
+      }
+      if (residual) v += *reinterpret_cast<const f32x4 *>(residual + (size_t)row * COUT + 4 * c);
+      if (relu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.0f ? v[j] : 0.0f;
+      }
+      *reinterpret_cast<f32x4 *>(out + (size_t)row * COUT + 4 * c) = v;
+    }
+    __syncthreads();  // s_out / lists are reused by the next tile
+    if (prof) pt[6] += (unsigned long long)__builtin_amdgcn_s_memtime() - tq;  // epilogue
+  }
+  if (prof && threadIdx.x == 0) {
+    unsigned long long tk1 = __builtin_amdgcn_s_memtime(), tr1 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < 8; ++i) atomicAdd(&prof[i], pt[i]);
+    atomicAdd(&prof[8], tk1 - tk0);   // cycles in kernel (this workgroup)
+    atomicAdd(&prof[9], tr1 - tr0);   // 100 MHz ticks in kernel
+    atomicAdd(&prof[10], 1ull);       // workgroups
+  }
+#undef SF_STAMP
+}
+
 // (K, cin, cout) -> fragment order [k][nb][t][lane] float4, element j = W[k][16t+4(lane>>4)+j][16nb+(lane&15)]
 __global__ void pack_filters_kernel(const float *__restrict__ w, int K, int cin, int cinp, int cout,
                                     float *__restrict__ wp) {
@@ -475,6 +844,44 @@ int launch(const ConvArgs &a, int balance_default) {
   return SF_OK;
 }
 
+template <int CIN, int COUT, int TM, int AM, int WAVES>
+int launch_wide(const ConvArgs &a, int balance_default) {
+  constexpr bool ok = (COUT / 16) % WAVES == 0 && (AM * (CIN / 4)) % (WAVES * 64) == 0 && CIN >= 32;
+  if constexpr (!ok) {  // shape outside the wide kernel: the general kernel at its usual tile
+    return launch<CIN, COUT, 80, 64, 4, 1>(a, 1);
+  } else {
+    using S = WideShape<CIN, COUT, TM, AM, WAVES>;
+    constexpr size_t lds = (size_t)(TM + 1) * S::OST * 4 + (size_t)2 * AM * CIN * 4 +
+                           (size_t)kMaxK * S::TMP * 5 + (size_t)kMaxK * 4 + (S::NMETA + 1) * 4 + 64;
+    static_assert(lds <= 160 * 1024, "tile does not fit LDS");
+    static int slots = 0;
+    if (slots == 0) {
+      int dev = 0, cus = 256, per_cu = 1;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+        cus = prop.multiProcessorCount;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
+              &per_cu, sparse_conv_f32_wide_kernel<CIN, COUT, TM, AM, WAVES>, WAVES * 64, 0) !=
+              hipSuccess ||
+          per_cu < 1)
+        per_cu = 1;
+      int by_lds = (int)((160 * 1024) / lds);
+      if (per_cu > by_lds) per_cu = by_lds < 1 ? 1 : by_lds;
+      slots = cus * per_cu;
+    }
+    const int balance = env_balance(balance_default);
+    int tiles = sf_div_up(a.n_out_bound, balance ? 32 : TM);
+    int cap = balance ? slots : 4096;
+    int grid = tiles < cap ? tiles : cap;
+    hipLaunchKernelGGL((sparse_conv_f32_wide_kernel<CIN, COUT, TM, AM, WAVES>), dim3(grid),
+                       dim3(WAVES * 64), 0, a.st, a.feat, a.nbr, a.nbr_stride, a.K, a.k_first, a.wpk,
+                       a.scale, a.shift, a.residual, a.relu, a.out, a.n_out_dev, a.n_out_bound,
+                       balance, g_conv_prof);
+    SF_CHECK_LAUNCH();
+    return SF_OK;
+  }
+}
+
 // Experiment hook: SF_CONV_CFG="tm,am,waves,abuf" overrides the per-shape default (read once).
 long env_cfg() {
   static long cfg = -2;
@@ -492,6 +899,9 @@ long env_cfg() {
 #define SF_CASE(tm, am, w, ab) \
   case SF_CFG(tm, am, w, ab):  \
     return launch<CIN, COUT, tm, am, w, ab>(a, bal)
+#define SF_CASE_W(tm, am, w) \
+  case SF_CFG(tm, am, w, 3):   \
+    return launch_wide<CIN, COUT, tm, am, w>(a, bal)  // "abuf" 3 = the wide kernel
 
 template <int CIN, int COUT>
 int launch_cfg(const ConvArgs &a) {
@@ -500,14 +910,18 @@ int launch_cfg(const ConvArgs &a) {
   if constexpr (big) {
     long cfg = env_cfg();
     int bal = 0;
-    if (cfg < 0) {  // measured best per shape (tools/sweep_conv.sh)
+    if (cfg < 0) {  // measured best per shape (tools/sweep_conv.sh); "abuf" 3 = wide kernel
       bal = 1;
-      if (CIN >= 128)
-        cfg = SF_CFG(96, 64, 8, 1);
-      else if (CIN >= 64)
-        cfg = SF_CFG(88, 64, 4, 1);
-      else
+      if (CIN >= 128) {
+        cfg = SF_CFG(96, 64, 8, 3);
+      } else if (COUT >= 128) {
+        cfg = SF_CFG(68, 64, 8, 3);
+        bal = 0;
+      } else if (COUT >= 64) {
+        cfg = SF_CFG(80, 64, 4, 3);
+      } else {
         cfg = SF_CFG(80, 64, 4, 1);
+      }
     }
     switch (cfg) {
       SF_CASE(64, 64, 4, 2);
@@ -522,6 +936,17 @@ int launch_cfg(const ConvArgs &a) {
       SF_CASE(96, 48, 4, 1);
       SF_CASE(96, 64, 8, 1);
       SF_CASE(128, 64, 8, 1);
+      SF_CASE_W(64, 64, 2);
+      SF_CASE_W(96, 64, 2);
+      SF_CASE_W(64, 64, 4);
+      SF_CASE_W(64, 48, 4);
+      SF_CASE_W(80, 64, 4);
+      SF_CASE_W(88, 64, 4);
+      SF_CASE_W(96, 48, 4);
+      SF_CASE_W(64, 64, 8);
+      SF_CASE_W(68, 64, 8);
+      SF_CASE_W(96, 64, 8);
+      SF_CASE_W(128, 64, 8);
     }
     sf_set_error("unknown SF_CONV_CFG %ld", cfg);
     return SF_ERR_BAD_ARG;
@@ -530,6 +955,7 @@ int launch_cfg(const ConvArgs &a) {
   }
 }
 #undef SF_CASE
+#undef SF_CASE_W
 
 template <int CIN>
 int dispatch_cout(int cout, const ConvArgs &a) {

@@ -56,7 +56,7 @@ def _flatten_encoder(enc):
 class LidarBackbone:
 
     def __init__(self, voxel_layer_cfg, encoder, device, max_points, batch_size=1,
-                 materialize_voxels=True, training=False):
+                 materialize_voxels=True, training=False, overlap=True):
         assert isinstance(encoder, SparseEncoder)
         L = self.L = _lib.lib()
         self.dev = torch.device(device)
@@ -70,6 +70,8 @@ class LidarBackbone:
         mv = mv if isinstance(mv, (tuple, list)) else (mv, mv)
         self.mv = int(mv[0] if training else mv[1])
         self.materialize = materialize_voxels
+        self.overlap = bool(overlap)      # coordinate phase on a second stream
+        self.side_stream = torch.cuda.Stream(device=self.dev) if self.overlap else None
         self.enc = encoder
         self.in_channels = encoder.in_channels
         self.F = None  # point feature count, fixed at first call
@@ -225,10 +227,22 @@ class LidarBackbone:
                 self.voxels.data_ptr() if self.materialize else None, s0['indices'].data_ptr(), 4,
                 b, self.num_points.data_ptr(), self.mean.data_ptr(), nf, self.cin_pad, c0,
                 s0['bound'], ovf, None, self.vox_ws.data_ptr(), self.vox_ws_bytes, st))
-        # ---- coordinate phase --------------------------------------------------------------
+        # ---- coordinate phase: on its own stream, forked after the voxelizer ---------------
+        # The hash / neighbour-table kernels are latency bound and need no LDS: they run in the
+        # shadow of the MFMA-bound convolutions of the earlier stages.  Each rulebook records an
+        # event; the feature phase waits for it before the first layer that uses the rulebook
+        # (under graph capture these become fork / join edges of the graph).
+        main = torch.cuda.current_stream(dev)
+        side = self.side_stream if self.overlap else main
+        ss = side.cuda_stream
+        if self.overlap:
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
         chk(L.sf_hash_build(s0['indices'].data_ptr(), c0, s0['bound'], _lib.i3(s0['shape']),
                             self.B, s0['keys'].data_ptr(), s0['vals'].data_ptr(), s0['cap'], ovf,
-                            st))
+                            ss))
+        rb_ready = []
         for rb in self.rulebooks:
             src, dst = self.sets[rb['src']], self.sets[rb['dst']]
             n_src, n_dst = c0 + 4 * rb['src'], c0 + 4 * rb['dst']
@@ -237,12 +251,17 @@ class LidarBackbone:
                     src['indices'].data_ptr(), n_src, src['bound'], self.B, _lib.i3(dst['shape']),
                     _lib.i3(rb['ks']), _lib.i3(rb['st']), _lib.i3(rb['pd']), dst['keys'].data_ptr(),
                     dst['vals'].data_ptr(), dst['cap'], dst['indices'].data_ptr(), dst['bound'],
-                    n_dst, ovf, self.rb_ws.data_ptr(), self.rb_ws_bytes, st))
+                    n_dst, ovf, self.rb_ws.data_ptr(), self.rb_ws_bytes, ss))
             chk(L.sf_neighbor_table(
                 dst['indices'].data_ptr(), n_dst, dst['bound'], self.B, _lib.i3(src['shape']),
                 _lib.i3(rb['ks']), _lib.i3(rb['st']), _lib.i3(rb['pd']), src['keys'].data_ptr(),
                 src['vals'].data_ptr(), src['cap'], 1 if rb['subm'] else 0, rb['nbr'].data_ptr(),
-                rb['stride'], st))
+                rb['stride'], ss))
+            if self.overlap:
+                e = torch.cuda.Event()
+                e.record(side)
+                rb_ready.append(e)
+        waited = set()
         # ---- feature phase -----------------------------------------------------------------
         x, x_ch = self.mean, self.cin_pad
         if voxel_features is not None:
@@ -266,6 +285,10 @@ class LidarBackbone:
                 residual = block_in
             cp = L.sf_conv_padded_cin(lay.cin)
             assert cp == x_ch, (cp, x_ch)
+            ri = self.rulebooks.index(rb)
+            if self.overlap and ri not in waited:
+                main.wait_event(rb_ready[ri])
+                waited.add(ri)
             chk(L.sf_sparse_conv_f32(
                 x.data_ptr(), cp, rb['nbr'].data_ptr(), rb['stride'], rb['K'],
                 (rb['K'] - 1) // 2 if rb['subm'] else -1, lay.packed.data_ptr(), lay.cout,
