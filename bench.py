@@ -110,6 +110,25 @@ def time_layers(bb, pts, vf, iters=5):
     return acc / iters  # ms per layer
 
 
+def measured_traffic(cin, cout):
+    """HBM-side bytes per launch of the conv instantiation, from the committed PMC passes
+    (profiles/r01_pmc_hbm_traffic.json: tools/pmc_traffic.sh, FETCH_SIZE doubled as the gfx950
+    note in MI355X_MICROARCH.md prescribes, WRITE_SIZE as read).  Counters cannot be collected
+    inside this process; None when the file has no such kernel."""
+    import re
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        table = json.load(f)
+    pat = re.compile(r'sparse_conv_f32(_wide)?_kernel<%d, %d,' % (cin, cout))
+    hits = [v for k, v in table.items() if pat.match(k)]
+    if not hits:
+        return None
+    n = sum(v['launches'] for v in hits)
+    return round(sum(v['traffic_bytes'] * v['launches'] for v in hits) / n, 1)
+
+
 def cpu_baseline(cfg, ecfg, sd, points, workload):
     """The oracle (port of the reference's CPU path) on one frame; returns frames/s."""
     from oracle import oracle as O
@@ -145,7 +164,7 @@ def main():
     ap.add_argument('--workload', default='nusc', choices=['nusc', 'waymo'])
     ap.add_argument('--frames', type=int, default=4, help='distinct synthetic frames per rank')
     ap.add_argument('--batch', type=int, default=1, help='frames per step (samples per batch)')
-    ap.add_argument('--streams', type=int, default=1,
+    ap.add_argument('--streams', type=int, default=2,
                     help='frames in flight per GPU (each on its own HIP stream and workspace)')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-overlap', action='store_true',
@@ -252,6 +271,7 @@ def main():
                 roofline = dict(bound='hbm', achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit='GB/s',
                                 frac=round(ach / PEAK_HBM_GBS, 4), traffic=None)
             roofline['kernel'] = f'sparse_conv_f32_kernel<{dom[0] if dom[0] > 8 else 8},{dom[1]}>'
+            roofline['traffic'] = measured_traffic(dom[0] if dom[0] > 8 else 8, dom[1])
             roofline['launches_per_frame'] = gd['launches']
             roofline['avg_launch_us'] = round(avg_s * 1e6, 2)
             roofline['algorithmic_flops_per_launch'] = fl

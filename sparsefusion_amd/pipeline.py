@@ -234,18 +234,20 @@ class LidarBackbone:
         # (under graph capture these become fork / join edges of the graph).
         main = torch.cuda.current_stream(dev)
         side = self.side_stream if self.overlap else main
-        ss = side.cuda_stream
-        if self.overlap:
+        chk(L.sf_hash_build(s0['indices'].data_ptr(), c0, s0['bound'], _lib.i3(s0['shape']),
+                            self.B, s0['keys'].data_ptr(), s0['vals'].data_ptr(), s0['cap'], ovf,
+                            st))
+        fork = self.overlap and len(self.rulebooks) > 1
+        if fork:
             ev = torch.cuda.Event()
             ev.record(main)
             side.wait_event(ev)
-        chk(L.sf_hash_build(s0['indices'].data_ptr(), c0, s0['bound'], _lib.i3(s0['shape']),
-                            self.B, s0['keys'].data_ptr(), s0['vals'].data_ptr(), s0['cap'], ovf,
-                            ss))
-        rb_ready = []
-        for rb in self.rulebooks:
+        rb_ready = {}
+        for ri, rb in enumerate(self.rulebooks):
             src, dst = self.sets[rb['src']], self.sets[rb['dst']]
             n_src, n_dst = c0 + 4 * rb['src'], c0 + 4 * rb['dst']
+            # the first rulebook feeds the very first layer: it stays on the main stream
+            ss = side.cuda_stream if (fork and ri > 0) else st
             if not rb['subm']:
                 chk(L.sf_conv_output_set(
                     src['indices'].data_ptr(), n_src, src['bound'], self.B, _lib.i3(dst['shape']),
@@ -257,10 +259,10 @@ class LidarBackbone:
                 _lib.i3(rb['ks']), _lib.i3(rb['st']), _lib.i3(rb['pd']), src['keys'].data_ptr(),
                 src['vals'].data_ptr(), src['cap'], 1 if rb['subm'] else 0, rb['nbr'].data_ptr(),
                 rb['stride'], ss))
-            if self.overlap:
+            if fork and ri > 0:
                 e = torch.cuda.Event()
                 e.record(side)
-                rb_ready.append(e)
+                rb_ready[ri] = e
         waited = set()
         # ---- feature phase -----------------------------------------------------------------
         x, x_ch = self.mean, self.cin_pad
@@ -286,7 +288,7 @@ class LidarBackbone:
             cp = L.sf_conv_padded_cin(lay.cin)
             assert cp == x_ch, (cp, x_ch)
             ri = self.rulebooks.index(rb)
-            if self.overlap and ri not in waited:
+            if ri in rb_ready and ri not in waited:
                 main.wait_event(rb_ready[ri])
                 waited.add(ri)
             chk(L.sf_sparse_conv_f32(
