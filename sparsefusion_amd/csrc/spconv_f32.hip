@@ -577,8 +577,8 @@ __device__ __forceinline__ void wide_phase(const float *__restrict__ feat,
   m1 = m2;
 }
 
-template <int CIN, int COUT, int TM, int AM, int WAVES>
-__global__ void __launch_bounds__(WAVES * 64)
+template <int CIN, int COUT, int TM, int AM, int WAVES, int MINW>
+__global__ void __launch_bounds__(WAVES * 64, MINW)
 sparse_conv_f32_wide_kernel(const float *__restrict__ feat, const int *__restrict__ nbr,
                             int nbr_stride, int K, int k_first, const float *__restrict__ wpk,
                             const float *__restrict__ scale, const float *__restrict__ shift,
@@ -754,6 +754,119 @@ sparse_conv_f32_wide_kernel(const float *__restrict__ feat, const int *__restric
 #undef SF_STAMP
 }
 
+// ---------------------------------------------------------------------------------------------
+// "Direct" variant for 3x3x3 kernels: no LDS, no barriers, no compaction.  A wave owns 16*MB
+// output rows and keeps their sums in the MFMA accumulators for the whole layer; per offset every
+// lane loads its own A fragment straight from the input row the neighbour table names (zeros
+// where there is none) and the filter fragments from L1/L2 (every wave reads the same 27 small
+// matrices).  It multiplies the empty (row, offset) slots too, so it pays where the matrix pipe
+// is not the bound (narrow layers) or where the per-phase bookkeeping of the tiled kernels costs
+// more than the empty slots (64 channels).  Summation order per output: centre offset first,
+// then k ascending, channel groups ascending -- fixed, no atomics.
+template <int CIN, int COUT, int MB, int D1>
+__global__ void __launch_bounds__(256)
+sparse_conv_f32_direct_kernel(const float *__restrict__ feat, const int *__restrict__ nbr,
+                              int nbr_stride, int k_first, const float *__restrict__ wpk,
+                              const float *__restrict__ scale, const float *__restrict__ shift,
+                              const float *__restrict__ residual, int relu, float *__restrict__ out,
+                              const int *n_out_dev, int n_out_bound) {
+  constexpr int K = 27;
+  constexpr int CINP = CIN < 16 ? 16 : CIN;
+  constexpr int T = CINP / 16, CH = CIN / 4, NB = COUT / 16, ROWS = 16 * MB;
+  constexpr int D0 = 2;  // neighbour indices are loaded D0 offsets ahead of the rows they name
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, ln = lane & 15;
+  const int n_out = load_n(n_out_dev, n_out_bound);
+  const int row0 = (blockIdx.x * 4 + wave) * ROWS;
+  if (row0 >= n_out) return;
+  const f32x4 *__restrict__ wp4 = reinterpret_cast<const f32x4 *>(wpk);
+  const int kf = (k_first >= 0 && k_first < K) ? k_first : -1;
+
+  f32x4 acc[MB][NB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // every array below is indexed by compile-time constants only (the loop is fully unrolled):
+  // each element is a value with a short live range, not storage
+  int idx[K][MB];
+  f32x4 a[K][MB][T];
+  f32x4 b[K][NB][T];
+#pragma unroll
+  for (int i = -(D0 + D1); i < K; ++i) {
+    if (i + D0 + D1 < K) {  // neighbour indices of offset i + D0 + D1 (visit order)
+      const int kk = i + D0 + D1;
+      const int k = kf < 0 ? kk : (kk == 0 ? kf : (kk <= kf ? kk - 1 : kk));
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        // branch-free (rows past the end re-read the last row's entry, empty slots read row
+        // 0): straight-line code keeps the compiler's outstanding-load counts exact, so the
+        // loads issued for later offsets really stay in flight under the MFMAs
+        const int r = row0 + mb * 16 + ln;
+        const int v = nbr[(size_t)k * nbr_stride + (r < n_out ? r : n_out - 1)];
+        idx[kk][mb] = (r < n_out) ? v : -1;
+      }
+    }
+    if (i + D1 >= 0 && i + D1 < K) {  // rows and filter fragments of offset i + D1
+      const int kk = i + D1;
+      const int k = kf < 0 ? kk : (kk == 0 ? kf : (kk <= kf ? kk - 1 : kk));
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int t = 0; t < T; ++t) b[kk][nb][t] = wp4[(((size_t)k * NB + nb) * T + t) * 64 + lane];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const int ix = idx[kk][mb];  // zeroed at use, not here: the load stays in flight
+          a[kk][mb][t] = *reinterpret_cast<const f32x4 *>(
+              feat + (size_t)(ix >= 0 ? ix : 0) * CIN + 16 * t + ((CIN >= 16 || g < CH) ? 4 * g : 0));
+        }
+    }
+    if (i >= 0) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const bool ok = idx[i][mb] >= 0 && (CIN >= 16 || g < CH);
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a[i][mb][t][j] = ok ? a[i][mb][t][j] : 0.0f;
+      }
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+              acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][mb][t][j], b[i][nb][t][j],
+                                                                 acc[mb][nb], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  // epilogue: accumulator element r of lane (g, ln) is C[4g + r][ln]
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int col = nb * 16 + ln;
+    const float sc = scale ? scale[col] : 1.0f, sh = scale ? shift[col] : 0.0f;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + mb * 16 + 4 * g + r;
+        if (row < n_out) {
+          float v = acc[mb][nb][r] * sc + sh;
+          if (residual) v += residual[(size_t)row * COUT + col];
+          if (relu) v = v > 0.0f ? v : 0.0f;
+          out[(size_t)row * COUT + col] = v;
+        }
+      }
+  }
+}
+
 // (K, cin, cout) -> fragment order [k][nb][t][lane] float4, element j = W[k][16t+4(lane>>4)+j][16nb+(lane&15)]
 __global__ void pack_filters_kernel(const float *__restrict__ w, int K, int cin, int cinp, int cout,
                                     float *__restrict__ wp) {
@@ -844,7 +957,7 @@ int launch(const ConvArgs &a, int balance_default) {
   return SF_OK;
 }
 
-template <int CIN, int COUT, int TM, int AM, int WAVES>
+template <int CIN, int COUT, int TM, int AM, int WAVES, int MINW = 1>
 int launch_wide(const ConvArgs &a, int balance_default) {
   constexpr bool ok = (COUT / 16) % WAVES == 0 && (AM * (CIN / 4)) % (WAVES * 64) == 0 && CIN >= 32;
   if constexpr (!ok) {  // shape outside the wide kernel: the general kernel at its usual tile
@@ -861,7 +974,7 @@ int launch_wide(const ConvArgs &a, int balance_default) {
       if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
         cus = prop.multiProcessorCount;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
-              &per_cu, sparse_conv_f32_wide_kernel<CIN, COUT, TM, AM, WAVES>, WAVES * 64, 0) !=
+              &per_cu, sparse_conv_f32_wide_kernel<CIN, COUT, TM, AM, WAVES, MINW>, WAVES * 64, 0) !=
               hipSuccess ||
           per_cu < 1)
         per_cu = 1;
@@ -873,13 +986,24 @@ int launch_wide(const ConvArgs &a, int balance_default) {
     int tiles = sf_div_up(a.n_out_bound, balance ? 32 : TM);
     int cap = balance ? slots : 4096;
     int grid = tiles < cap ? tiles : cap;
-    hipLaunchKernelGGL((sparse_conv_f32_wide_kernel<CIN, COUT, TM, AM, WAVES>), dim3(grid),
+    hipLaunchKernelGGL((sparse_conv_f32_wide_kernel<CIN, COUT, TM, AM, WAVES, MINW>), dim3(grid),
                        dim3(WAVES * 64), 0, a.st, a.feat, a.nbr, a.nbr_stride, a.K, a.k_first, a.wpk,
                        a.scale, a.shift, a.residual, a.relu, a.out, a.n_out_dev, a.n_out_bound,
                        balance, g_conv_prof);
     SF_CHECK_LAUNCH();
     return SF_OK;
   }
+}
+
+template <int CIN, int COUT, int MB, int D1>
+int launch_direct(const ConvArgs &a) {
+  const int rows_per_block = 16 * MB * 4;
+  hipLaunchKernelGGL((sparse_conv_f32_direct_kernel<CIN, COUT, MB, D1>),
+                     dim3(sf_div_up(a.n_out_bound, rows_per_block)), dim3(256), 0, a.st, a.feat,
+                     a.nbr, a.nbr_stride, a.k_first, a.wpk, a.scale, a.shift, a.residual, a.relu,
+                     a.out, a.n_out_dev, a.n_out_bound);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
 }
 
 // Experiment hook: SF_CONV_CFG="tm,am,waves,abuf" overrides the per-shape default (read once).
@@ -903,8 +1027,39 @@ long env_cfg() {
   case SF_CFG(tm, am, w, 3):   \
     return launch_wide<CIN, COUT, tm, am, w>(a, bal)  // "abuf" 3 = the wide kernel
 
+// Experiment hook: SF_CONV_DIRECT="mb,d1[,mincin,maxcin]" sends 27-offset layers with cin in the
+// range (default: all that are instantiated) to the direct kernel.
+int env_direct(int cin) {
+  static int cfg = -2, lo = 0, hi = 1 << 30;
+  if (cfg == -2) {
+    cfg = -1;
+    const char *e = getenv("SF_CONV_DIRECT");
+    int mb, d1;
+    if (e) {
+      int n = sscanf(e, "%d,%d,%d,%d", &mb, &d1, &lo, &hi);
+      if (n >= 2) cfg = mb * 10 + d1;
+      if (n < 4) hi = 1 << 30;
+      if (n < 3) lo = 0;
+    }
+  }
+  return (cin >= lo && cin <= hi) ? cfg : -1;
+}
+
 template <int CIN, int COUT>
 int launch_cfg(const ConvArgs &a) {
+  if constexpr (CIN <= 64 && COUT <= 64 && (COUT == CIN || COUT == 2 * CIN)) {
+    if (a.K == 27) {
+      int d = env_direct(CIN);
+      // measured (tools/sweep_direct.sh): the direct kernel wins for the narrow SubM layers
+      if (d == -1 && getenv("SF_CONV_DIRECT") == nullptr && CIN <= 32 && COUT <= 32) d = 12;
+      switch (d) {
+        case 12: return launch_direct<CIN, COUT, 1, 2>(a);
+        case 13: return launch_direct<CIN, COUT, 1, 3>(a);
+        case 14: return launch_direct<CIN, COUT, 1, 4>(a);
+        case 21: return launch_direct<CIN, COUT, 2, 1>(a);
+      }
+    }
+  }
   // shapes of the SparseEncoder's wide stages get the tuning variants
   constexpr bool big = CIN >= 32 && (COUT == CIN || COUT == 2 * CIN);
   if constexpr (big) {
@@ -940,6 +1095,10 @@ int launch_cfg(const ConvArgs &a) {
       SF_CASE_W(96, 64, 2);
       SF_CASE_W(64, 64, 4);
       SF_CASE_W(64, 48, 4);
+      case SF_CFG(64, 48, 4, 4):  // "abuf" 4 = wide kernel held to 3 waves per SIMD (3 blocks per CU)
+        return launch_wide<CIN, COUT, 64, 48, 4, 3>(a, bal);
+      case SF_CFG(72, 48, 4, 4):
+        return launch_wide<CIN, COUT, 72, 48, 4, 3>(a, bal);
       SF_CASE_W(80, 64, 4);
       SF_CASE_W(88, 64, 4);
       SF_CASE_W(96, 48, 4);
