@@ -189,6 +189,32 @@ SF_API int sf_dense_bev(const float *features, const int *indices, const int *n_
 SF_API int sf_pad_channels_f32(const float *src, int c_src, float *dst, int c_dst,
                                const int *n_dev, int n_bound, void *stream);
 
+/* ------------------------------------------------------------------ dynamic scatter -- */
+
+/* Per-dimension maximum of coors (n, ndim) i32 into max_dev[ndim] (device; -1 where n == 0 or all
+ * entries negative).  The reference sizes its linear-id space the same way
+ * (`coors.max(0) + 1`, mmdet3d/ops/voxel/src/scatter_points_cuda.cu:241). */
+SF_API int sf_coors_max(const int *coors, int n, int ndim, int *max_dev, void *stream);
+
+/* Workspace bytes of sf_dynamic_scatter for a coordinate space dims[ndim]; 0 if the space has more
+ * than 2^32 cells (or a dimension < 1). */
+SF_API size_t sf_dynamic_scatter_workspace(const int *dims, int ndim);
+
+/* Replaces voxel_layer.dynamic_point_to_voxel_forward (mmdet3d/ops/voxel/src/voxelization.h:96-108,
+ * scatter_points_cuda.cu:230-311): feats (n, c) f32 and coors (n, ndim) i32 are reduced into the
+ * unique non-negative coordinates, output rows in ascending linear-id order (= lexicographic in
+ * the coordinates).  reduce_type 0 sum, 1 mean, 2 max (the reference's reduce_t).  Every dims[i]
+ * must exceed every coordinate of dimension i.  Outputs, caller allocated for `capacity` rows:
+ * voxel_feats (capacity, c), voxel_coors (capacity, ndim), count (capacity) [points per voxel for
+ * mean, else zeros, as in the reference], point2voxel (n) [-1 for dropped points];
+ * *num_voxels_dev receives the number of voxels, *overflow_dev is raised if it exceeds capacity.
+ * Sums use float atomics (order dependent in the last bits, like the reference's; max is exact). */
+SF_API int sf_dynamic_scatter(const float *feats, const int *coors, int n, int c, int ndim,
+                              const int *dims, int reduce_type, float *voxel_feats,
+                              int *voxel_coors, int *point2voxel, int *count, int capacity,
+                              int *num_voxels_dev, int *overflow_dev, void *ws, size_t ws_bytes,
+                              void *stream);
+
 #ifdef __cplusplus
 }
 #endif

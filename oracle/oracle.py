@@ -50,6 +50,9 @@ def lib():
         L.sfo_indice_conv.restype = C.c_int
         L.sfo_bn_act.argtypes = [_f32p, C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_float,
                                  C.c_void_p, C.c_int]
+        L.sfo_dynamic_scatter.argtypes = [_f32p, _i32p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p,
+                                          _i32p, _i32p, _i32p]
+        L.sfo_dynamic_scatter.restype = C.c_int
         L.sfo_dense_bev.argtypes = [_f32p, _i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_int, _f32p]
         L.sfo_num_threads.restype = C.c_int
@@ -228,6 +231,21 @@ def dense_bev(features, indices, batch, shape):
     out = np.zeros((batch, c * D, H, W), np.float32)
     lib().sfo_dense_bev(features, _i32(indices), features.shape[0], c, batch, D, H, W, out)
     return out
+
+
+def dynamic_scatter(feats, coors, reduce_type='max'):
+    """dynamic_point_to_voxel_forward (scatter_points_cuda.cu:230-311):
+    -> voxel_feats (M,C), voxel_coors (M,ndim), point2voxel (N,), count (M,)."""
+    feats, coors = _f32(feats), _i32(coors)
+    n, c = feats.shape
+    ndim = coors.shape[1]
+    vf = np.zeros((max(n, 1), c), np.float32)
+    vc = np.zeros((max(n, 1), ndim), np.int32)
+    p2v = np.zeros((max(n, 1),), np.int32)
+    cnt = np.zeros((max(n, 1),), np.int32)
+    m = lib().sfo_dynamic_scatter(feats, coors, n, c, ndim, {'sum': 0, 'mean': 1, 'max': 2}[reduce_type],
+                                  vf, vc, p2v, cnt)
+    return vf[:m], vc[:m], p2v[:n], cnt[:m]
 
 
 def weight_to_kio(w, ksize, in_channels, out_channels):

@@ -380,6 +380,79 @@ SFO_API void sfo_dense_bev(const float *feat, const int *idx4, int n, int c, int
   }
 }
 
+/* dynamic_point_to_voxel_forward: mmdet3d/ops/voxel/src/scatter_points_cuda.cu:230-311 restated
+ * sequentially.  Linear id per point with dims = per-dimension max + 1 (:241, coors_id_kernel
+ * :80-95, -1 if any coordinate is negative); unique ids ascending = output rows (argsort :258,
+ * segment heads :97-115, cumsum :271); out_coors = the point's coordinates (:129-133);
+ * sum / mean / max over the member points (:135-148, mean divides by the count :303-305; the
+ * count array stays zero for sum and max as in the reference).  Sums run in point order in fp32
+ * (the reference's atomics have no fixed order).  reduce: 0 sum, 1 mean, 2 max.
+ * Outputs sized for n rows; returns the number of voxels. */
+static int cmp_i64(const void *a, const void *b) {
+  long long x = *(const long long *)a, y = *(const long long *)b;
+  return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+SFO_API int sfo_dynamic_scatter(const float *feats, const int *coors, int n, int c, int ndim,
+                                int reduce, float *vfeats, int *vcoors, int *p2v, int *count) {
+  if (n == 0) return 0;
+  long long dims[8];
+  for (int i = 0; i < ndim; ++i) {
+    int m = -1;
+    for (int x = 0; x < n; ++x)
+      if (coors[(size_t)x * ndim + i] > m) m = coors[(size_t)x * ndim + i];
+    dims[i] = (long long)m + 1;
+  }
+  long long *ids = (long long *)malloc(sizeof(long long) * (size_t)n);
+  long long *uniq = (long long *)malloc(sizeof(long long) * (size_t)n);
+  int m = 0;
+  for (int x = 0; x < n; ++x) {
+    long long id = 0;
+    for (int i = 0; i < ndim && id != -1; ++i) {
+      long long t = coors[(size_t)x * ndim + i];
+      id = (t < 0) ? -1 : id * dims[i] + t;
+    }
+    ids[x] = id;
+    if (id >= 0) uniq[m++] = id;
+  }
+  qsort(uniq, (size_t)m, sizeof(long long), cmp_i64);
+  int nv = 0;
+  for (int i = 0; i < m; ++i)
+    if (i == 0 || uniq[i] != uniq[i - 1]) uniq[nv++] = uniq[i];
+  for (int v = 0; v < nv; ++v) {
+    count[v] = 0;
+    for (int q = 0; q < c; ++q) vfeats[(size_t)v * c + q] = (reduce == 2) ? -INFINITY : 0.0f;
+  }
+  int *members = (int *)calloc((size_t)nv > 0 ? (size_t)nv : 1, sizeof(int));
+  for (int x = 0; x < n; ++x) {
+    if (ids[x] < 0) {
+      p2v[x] = -1;
+      continue;
+    }
+    int lo = 0, hi = nv - 1;
+    while (lo < hi) {
+      int mid = (lo + hi) / 2;
+      if (uniq[mid] < ids[x]) lo = mid + 1; else hi = mid;
+    }
+    p2v[x] = lo;
+    members[lo]++;
+    for (int i = 0; i < ndim; ++i) vcoors[(size_t)lo * ndim + i] = coors[(size_t)x * ndim + i];
+    for (int q = 0; q < c; ++q) {
+      float f = feats[(size_t)x * c + q], *o = &vfeats[(size_t)lo * c + q];
+      if (reduce == 2) *o = fmaxf(f, *o); else *o = *o + f;
+    }
+  }
+  if (reduce == 1)
+    for (int v = 0; v < nv; ++v) {
+      count[v] = members[v];
+      for (int q = 0; q < c; ++q) vfeats[(size_t)v * c + q] /= (float)members[v];
+    }
+  free(members);
+  free(uniq);
+  free(ids);
+  return nv;
+}
+
 SFO_API int sfo_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

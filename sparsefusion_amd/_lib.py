@@ -45,6 +45,10 @@ SIGNATURES = {
                                 _i, _vp]),
     'sf_dense_bev': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'sf_pad_channels_f32': (_i, [_vp, _i, _vp, _i, _vp, _i, _vp]),
+    'sf_coors_max': (_i, [_vp, _i, _i, _vp, _vp]),
+    'sf_dynamic_scatter_workspace': (_sz, [C.POINTER(C.c_int), _i]),
+    'sf_dynamic_scatter': (_i, [_vp, _vp, _i, _i, _i, C.POINTER(C.c_int), _i, _vp, _vp, _vp, _vp,
+                                _i, _vp, _vp, _vp, _sz, _vp]),
 }
 
 
