@@ -89,6 +89,15 @@ SF_API int sf_voxel_mean(const float *voxels, const int *num_points_per_voxel, c
                          int m_bound, int max_points, int f, int num_features, float *out,
                          int out_stride, void *stream);
 
+/* Replaces SparseFusionDetector.extract_voxel_heights (mmdet3d/models/detectors/sparsefusion.py:73-112):
+ * min_height / max_height (batch, ny, nx) f32 = per BEV cell (y / out_size_factor,
+ * x / out_size_factor) minimum / maximum point z over the voxels in the cell, a z of exactly 0
+ * counting as padding; cells without points keep the reference's sentinels +100 / -200.
+ * coors4 rows are (b, z, y, x); the sentinel fill is part of the call. */
+SF_API int sf_voxel_heights(const float *voxels, const int *coors4, const int *m_dev, int m_bound,
+                            int max_points, int f, int batch, int ny, int nx, int out_size_factor,
+                            float *min_height, float *max_height, void *stream);
+
 /* ------------------------------------------------------------------ rulebook --------- */
 
 /* Slots (power of two) a coordinate hash table needs for up to n_bound distinct coordinates.

@@ -246,3 +246,74 @@ extern "C" int sf_dynamic_scatter(const float *feats, const int *coors, int n, i
   }
   return SF_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// extract_voxel_heights (mmdet3d/models/detectors/sparsefusion.py:73-112): per BEV cell
+// (b, y / osf, x / osf) the minimum and maximum point height over the voxels that fall in it;
+// a z of exactly 0 is a padding slot (sentinels +100 / -200, :82-86).  The reference loops 40
+// height slices with masked scatters; here one thread reduces one voxel's slots and issues two
+// order-preserving integer atomics.  HBM-bound: the z column of the voxel tensor is read once.
+namespace {
+
+__global__ void heights_init_kernel(float *__restrict__ mn, float *__restrict__ mx, long long cells) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < cells;
+       e += (long long)gridDim.x * blockDim.x) {
+    mn[e] = 100.0f;
+    mx[e] = -200.0f;
+  }
+}
+
+__device__ __forceinline__ void atomic_min_f32(float *addr, float v) {
+  if (v >= 0.0f)
+    atomicMin(reinterpret_cast<int *>(addr), __float_as_int(v));
+  else
+    atomicMax(reinterpret_cast<unsigned *>(addr), __float_as_uint(v));
+}
+
+__global__ void heights_kernel(const float *__restrict__ voxels, const int *__restrict__ coors4,
+                               const int *m_dev, int m_bound, int max_points, int f, int batch,
+                               int ny, int nx, int osf, float *__restrict__ mn,
+                               float *__restrict__ mx) {
+  int m = m_dev ? *m_dev : m_bound;
+  if (m > m_bound) m = m_bound;
+  for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < m; v += gridDim.x * blockDim.x) {
+    float lo = 100.0f, hi = -200.0f;
+    for (int p = 0; p < max_points; ++p) {
+      const float z = voxels[((size_t)v * max_points + p) * f + 2];
+      const float zmin = (z == 0.0f) ? 100.0f : z;           // voxels_[voxels_==0] = 100   (:82)
+      const float zmax = (zmin == 100.0f) ? -200.0f : z;     // voxels_[voxels_==100] = -200 (:84)
+      lo = zmin < lo ? zmin : lo;
+      hi = zmax > hi ? zmax : hi;
+    }
+    const int4 c = reinterpret_cast<const int4 *>(coors4)[v];
+    const int cy = c.z / osf, cx = c.w / osf;
+    if (c.x < 0 || c.x >= batch || cy < 0 || cy >= ny || cx < 0 || cx >= nx) continue;
+    const size_t cell = ((size_t)c.x * ny + cy) * nx + cx;
+    atomic_min_f32(&mn[cell], lo);
+    atomic_max_f32(&mx[cell], hi);
+  }
+}
+
+}  // namespace
+
+extern "C" int sf_voxel_heights(const float *voxels, const int *coors4, const int *m_dev,
+                                int m_bound, int max_points, int f, int batch, int ny, int nx,
+                                int out_size_factor, float *min_height, float *max_height,
+                                void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  SF_CHECK_ARG(m_bound >= 0 && max_points >= 1 && f >= 3 && batch >= 1 && ny >= 1 && nx >= 1 &&
+                   out_size_factor >= 1,
+               "bad shape (need >= 3 point features: z is column 2)");
+  SF_CHECK_ARG(min_height && max_height, "output pointer is NULL");
+  const long long cells = (long long)batch * ny * nx;
+  hipLaunchKernelGGL(heights_init_kernel, dim3(sf_grid(cells, 256)), dim3(256), 0, st, min_height,
+                     max_height, cells);
+  SF_CHECK_LAUNCH();
+  if (m_bound == 0) return SF_OK;
+  SF_CHECK_ARG(voxels && coors4, "voxels / coors is NULL");
+  hipLaunchKernelGGL(heights_kernel, dim3(sf_grid(m_bound, 256)), dim3(256), 0, st, voxels, coors4,
+                     m_dev, m_bound, max_points, f, batch, ny, nx, out_size_factor, min_height,
+                     max_height);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
