@@ -37,9 +37,10 @@ from sparsefusion_amd.sparse_encoder import SparseEncoder  # noqa: E402
 
 PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA dense peak (no 2:1 sparsity)
 
 
-def build_backbone(workload, dev, batch, max_points, overlap=True):
+def build_backbone(workload, dev, batch, max_points, overlap=True, dtype='f32'):
     cfg = configs.NUSC if workload == 'nusc' else configs.WAYMO
     ecfg = dict(cfg['pts_middle_encoder'])
     ecfg.pop('type')
@@ -50,7 +51,7 @@ def build_backbone(workload, dev, batch, max_points, overlap=True):
     enc.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
     enc = enc.to(dev).eval()
     bb = LidarBackbone(cfg['pts_voxel_layer'], enc, dev, max_points, batch_size=batch,
-                       overlap=overlap)
+                       overlap=overlap, dtype=dtype)
     return cfg, ecfg, sd, enc, bb
 
 
@@ -68,9 +69,11 @@ def layer_work(bb):
         P, n_out = pairs[i], counts[rb['dst']]
         cin = lay.cin
         res = 1 if lay.residual_from == 'add' else 0
+        si = 2.0 if lay.bf16 else 4.0                              # input / residual element bytes
+        so = 2.0 if lay.out_dtype == torch.bfloat16 else 4.0       # output element bytes
         rows.append(dict(cin=cin, cout=lay.cout, subm=rb['subm'], K=rb['K'], pairs=P, n_out=n_out,
-                         flops=2.0 * P * cin * lay.cout,
-                         bytes=P * cin * 4.0 + n_out * lay.cout * 4.0 * (1 + res) + P * 8.0))
+                         bf16=bool(lay.bf16), flops=2.0 * P * cin * lay.cout,
+                         bytes=P * cin * si + n_out * lay.cout * (so + si * res) + P * 8.0))
     return rows, counts
 
 
@@ -78,23 +81,25 @@ def time_layers(bb, pts, vf, iters=5):
     """Mean launch duration of every conv layer, HIP events on the launch stream (eager)."""
     import sparsefusion_amd._lib as _lib
     L = _lib.lib()
-    real = L.sf_sparse_conv_f32
     evs = []
 
     class Shim:
         def __getattr__(self, name):
             return getattr(L, name)
 
-    def wrapped(*a):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        rc = real(*a)
-        e1.record()
-        evs.append((e0, e1))
-        return rc
+    def timed(real):
+        def wrapped(*a):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = real(*a)
+            e1.record()
+            evs.append((e0, e1))
+            return rc
+        return wrapped
 
     shim = Shim()
-    shim.__dict__['sf_sparse_conv_f32'] = wrapped
+    shim.__dict__['sf_sparse_conv_f32'] = timed(L.sf_sparse_conv_f32)
+    shim.__dict__['sf_sparse_conv_bf16'] = timed(L.sf_sparse_conv_bf16)
     nl = len(bb.layers)
     acc = np.zeros(nl)
     old = bb.L
@@ -166,6 +171,9 @@ def main():
     ap.add_argument('--batch', type=int, default=1, help='frames per step (samples per batch)')
     ap.add_argument('--streams', type=int, default=2,
                     help='frames in flight per GPU (each on its own HIP stream and workspace)')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
+                    help="f32 = the headline config (BASELINE configs[1]); bf16 = configs[2] "
+                         "(bf16 MFMA, fp32 accumulation; use with --batch 8)")
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-overlap', action='store_true',
                     help='coordinate phase on the main stream instead of a forked one')
@@ -190,11 +198,12 @@ def main():
     ids = sharding.frames_for_rank(rank, world, world * args.frames * B)
     host_frames = [gen(i) for i in ids]
     max_pts = max(p.shape[0] for p in host_frames)
-    cfg, ecfg, sd, enc, bb = build_backbone(args.workload, dev, B, max_pts, not args.no_overlap)
+    cfg, ecfg, sd, enc, bb = build_backbone(args.workload, dev, B, max_pts, not args.no_overlap,
+                                            args.dtype)
     # frames in flight: independent frames on independent streams fill each other's tail rounds
     # and barrier bubbles; every stream has its own workspace, weights are shared
     lanes = [bb] + [LidarBackbone(cfg['pts_voxel_layer'], enc, dev, max_pts, batch_size=B,
-                                  overlap=not args.no_overlap)
+                                  overlap=not args.no_overlap, dtype=args.dtype)
                     for _ in range(args.streams - 1)]
     streams = [torch.cuda.Stream(device=dev) for _ in lanes]
     frames = [[torch.from_numpy(host_frames[f * B + b]).to(dev) for b in range(B)]
@@ -249,7 +258,7 @@ def main():
                 raise SystemExit('overflow flag set: a bound was exceeded')
             groups = {}
             for w, t in zip(work, ms):
-                gkey = (w['cin'], w['cout'])
+                gkey = (w['cin'], w['cout'], w['bf16'])
                 g_ = groups.setdefault(gkey, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
                 g_['ms'] += t
                 g_['flops'] += w['flops']
@@ -260,18 +269,22 @@ def main():
             gd = groups[dom]
             avg_s = gd['ms'] / gd['launches'] * 1e-3
             fl, by = gd['flops'] / gd['launches'], gd['bytes'] / gd['launches']
-            t_mfma, t_hbm = fl / (PEAK_F32_MFMA_TFLOPS * 1e12), by / (PEAK_HBM_GBS * 1e9)
+            peak_mfma = PEAK_BF16_MFMA_TFLOPS if dom[2] else PEAK_F32_MFMA_TFLOPS
+            t_mfma, t_hbm = fl / (peak_mfma * 1e12), by / (PEAK_HBM_GBS * 1e9)
             if t_mfma >= t_hbm:
                 ach = fl / avg_s / 1e12
-                roofline = dict(bound='mfma', achieved=round(ach, 3), peak=PEAK_F32_MFMA_TFLOPS,
-                                unit='TFLOP/s', frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                roofline = dict(bound='mfma', achieved=round(ach, 3), peak=peak_mfma,
+                                unit='TFLOP/s', frac=round(ach / peak_mfma, 4),
                                 traffic=None)
             else:
                 ach = by / avg_s / 1e9
                 roofline = dict(bound='hbm', achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit='GB/s',
                                 frac=round(ach / PEAK_HBM_GBS, 4), traffic=None)
-            roofline['kernel'] = f'sparse_conv_f32_kernel<{dom[0] if dom[0] > 8 else 8},{dom[1]}>'
-            roofline['traffic'] = measured_traffic(dom[0] if dom[0] > 8 else 8, dom[1])
+            if dom[2]:
+                roofline['kernel'] = f'conv_bf16_kernel<{max(dom[0], 16)},{dom[1]}>'
+            else:
+                roofline['kernel'] = f'sparse_conv_f32_kernel<{dom[0] if dom[0] > 8 else 8},{dom[1]}>'
+                roofline['traffic'] = measured_traffic(dom[0] if dom[0] > 8 else 8, dom[1])
             roofline['launches_per_frame'] = gd['launches']
             roofline['avg_launch_us'] = round(avg_s * 1e6, 2)
             roofline['algorithmic_flops_per_launch'] = fl
@@ -279,22 +292,25 @@ def main():
             tot_fl, tot_by = sum(w['flops'] for w in work), sum(w['bytes'] for w in work)
             detail = dict(counts=counts[:-1], layers=work, conv_ms_per_frame=float(ms.sum()),
                           frame_flops=tot_fl, frame_bytes=tot_by,
-                          groups={f'{k[0]}x{k[1]}': v for k, v in groups.items()},
+                          groups={f'{k[0]}x{k[1]}' + ('b' if k[2] else ''): v
+                                  for k, v in groups.items()},
                           workspace_bytes=bb.memory_bytes())
 
     ms_per_step = elapsed / args.steps * 1e3
     value = world * args.steps * B / elapsed
+    prec = 'fp32' if args.dtype == 'f32' else ('bf16 storage + bf16 MFMA with fp32 accumulation '
+                                               '(first layer fp32)')
     if rank == 0:
         line = {
             'metric': 'LiDAR frames/sec (voxelize+SparseEncoder fwd)',
             'value': round(value, 2), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': ('nuScenes-shaped 10-sweep frame (sparsefusion_nusc_voxel_LC_r50: '
-                                    '0.075 m voxels, sparse_shape 41x1440x1440), fp32, single frame '
+                                    f'0.075 m voxels, sparse_shape 41x1440x1440), {prec}, {B} frame(s) '
                                     'per step' if args.workload == 'nusc' else
                                     'Waymo-shaped stress frame (transfusion_waymo_voxel_L: 0.1 m '
-                                    'voxels, 41x1504x1504, 64-ch encoder input), fp32'),
+                                    f'voxels, 41x1504x1504, 64-ch encoder input), {prec}'),
                        'frames_per_step': B, 'distinct_frames_per_rank': args.frames,
                        'points_per_frame': int(np.mean([p.shape[0] for p in host_frames])),
                        'voxels_frame0': detail['counts'][0] if detail else None,
@@ -307,7 +323,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cb, bev_cpu = cpu_baseline(cfg, ecfg, sd, host_frames[0], args.workload)
             line['cpu_baseline'] = cb
-            if args.workload == 'nusc' and B == 1:  # same frame: the GPU result must match it
+            if args.workload == 'nusc' and B == 1 and args.dtype == 'f32':  # same frame, same math
                 with torch.no_grad():
                     got = bb.enqueue(frames[0], vf).cpu().numpy()
                 err = float(np.abs(got - bev_cpu).max() / max(np.abs(bev_cpu).max(), 1e-30))

@@ -186,6 +186,37 @@ SF_API int sf_sparse_conv_f32(const float *features_in, int cin_padded, const in
                               int relu, float *out, const int *n_out_dev, int n_out_bound,
                               void *stream);
 
+/* ---- bf16 storage / bf16 MFMA / fp32 accumulation (BASELINE.json configs[2]) ----------
+ * The reference reaches reduced precision through mmcv's auto_fp16 on SparseEncoder.forward
+ * (mmdet3d/models/middle_encoders/sparse_encoder.py:53,95: fp16_enabled casts voxel_features to
+ * half and every spconv layer then runs in half); here the reduced type is bf16 and the cast is
+ * explicit.  Feature matrices are (n, c) bf16 row-major; scale/shift stay fp32. */
+
+/* Channel count a bf16 feature matrix must be padded to as conv INPUT (16, 32, 64 or 128), or
+ * -1 if unsupported. */
+SF_API int sf_conv_padded_cin_bf16(int cin);
+
+/* Filters (K, cin, cout) f32 -> bf16 (round to nearest even) in the MFMA fragment order of
+ * sf_sparse_conv_bf16.  w_packed holds K * sf_conv_padded_cin_bf16(cin) * cout bf16 values. */
+SF_API int sf_pack_filters_bf16(const float *w_kio, int K, int cin, int cout, void *w_packed,
+                                void *stream);
+
+/* src (n, c_src) f32 -> dst (n, c_dst) bf16, round to nearest even, columns >= c_src zero: the
+ * explicit form of the `.half()` cast auto_fp16 applies to voxel_features (sparse_encoder.py:95). */
+SF_API int sf_cast_f32_bf16(const float *src, int c_src, void *dst, int c_dst, const int *n_dev,
+                            int n_bound, void *stream);
+
+/* sf_sparse_conv_f32 with bf16 features / filters / residual and fp32 accumulation and epilogue
+ * (indiceConv<at::Half>, spconv_ops.h:260-361 + the fused BN/residual/ReLU tail).  features_in is
+ * (n_in_bound, cin_padded) bf16 -- n_in_bound rows must be addressable (the gather is bounds
+ * checked against it and the table must stay below 2 GiB); out is (n_out, cout) bf16, or fp32
+ * if out_is_f32 (the last layer feeds sf_dense_bev).  residual is (n_out, cout) bf16 or NULL. */
+SF_API int sf_sparse_conv_bf16(const void *features_in, int n_in_bound, int cin_padded,
+                               const int *nbr, int nbr_stride, int K, int k_first,
+                               const void *w_packed, int cout, const float *scale,
+                               const float *shift, const void *residual, int relu, void *out,
+                               int out_is_f32, const int *n_out_dev, int n_out_bound, void *stream);
+
 /* ------------------------------------------------------------------ dense BEV -------- */
 
 /* Replaces SparseConvTensor.dense() + view (mmdet3d/ops/spconv/structure.py:55-64,

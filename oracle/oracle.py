@@ -307,13 +307,35 @@ def _bn(sd, prefix):
             for k in ('weight', 'bias', 'running_mean', 'running_var')}
 
 
+def round_bf16(x):
+    """fp32 -> nearest bf16 (ties to even), returned as fp32: what v_cvt_pk_bf16_f32 / a torch
+    `.bfloat16()` cast does.  Finite inputs only."""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32)
+    r = (u + (np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1)))) & np.uint32(0xFFFF0000)
+    return r.view(np.float32)
+
+
 def sparse_encoder_forward(state_dict, voxel_features, coors, batch_size, sparse_shape,
-                           in_channels, bn_eps=1e-3, trace=None, **cfg):
+                           in_channels, bn_eps=1e-3, trace=None, bf16=False, **cfg):
     """SparseEncoder.forward (sparse_encoder.py:95-127) on the CPU oracle.
 
     state_dict: numpy arrays under the reference's key names.  `trace`, if a dict, receives
-    per-layer rulebooks / features for parity tests."""
+    per-layer rulebooks / features for parity tests.
+
+    bf16=True restates WHERE the bf16 path of the HIP library rounds (the reference's analogue is
+    auto_fp16, sparse_encoder.py:53,95): the first layer runs in fp32, its output and the output
+    of every later layer but the last are rounded to bf16, and the filters of every layer but the
+    first are rounded to bf16; sums, BatchNorm, residual add and ReLU stay fp32."""
     specs = encoder_layer_specs(in_channels, **cfg)
+    n_conv = [0]
+    total_conv = sum(1 if sp['kind'] == 'convmodule' else 2 for sp in specs)
+
+    def wq(w):            # filters of the layer about to run
+        n_conv[0] += 1
+        return round_bf16(w) if (bf16 and n_conv[0] > 1) else w
+
+    def aq(y):            # activations the layer that just ran writes
+        return round_bf16(y) if (bf16 and n_conv[0] < total_conv) else y
     feats = _f32(voxel_features)
     idx = _i32(coors)
     shape = list(sparse_shape)
@@ -333,9 +355,10 @@ def sparse_encoder_forward(state_dict, voxel_features, coors, batch_size, sparse
         p = spec['prefix']
         if spec['kind'] == 'convmodule':
             outids, pairs, num, oshape = rulebook(spec, idx, shape)
-            w = weight_to_kio(state_dict[f'{p}.0.weight'], spec['ksize'], spec['cin'], spec['cout'])
+            w = wq(weight_to_kio(state_dict[f'{p}.0.weight'], spec['ksize'], spec['cin'],
+                                 spec['cout']))
             y = indice_conv(feats, w, pairs, num, outids.shape[0], spec['subm'])
-            y = bn_act(y, _bn(state_dict, f'{p}.1'), bn_eps, None, True)
+            y = aq(bn_act(y, _bn(state_dict, f'{p}.1'), bn_eps, None, True))
             if trace is not None:
                 trace[p] = dict(in_indices=idx, in_shape=list(shape), outids=outids,
                                 out_shape=list(oshape), pairs=pairs, num=num, features=y)
@@ -343,13 +366,13 @@ def sparse_encoder_forward(state_dict, voxel_features, coors, batch_size, sparse
         else:  # SparseBasicBlock.forward, sparse_block.py:116-139
             identity = feats
             outids, pairs, num, oshape = rulebook(spec, idx, shape)
-            w1 = weight_to_kio(state_dict[f'{p}.conv1.weight'], 3, spec['cin'], spec['cout'])
+            w1 = wq(weight_to_kio(state_dict[f'{p}.conv1.weight'], 3, spec['cin'], spec['cout']))
             y = indice_conv(feats, w1, pairs, num, outids.shape[0], True)
-            y = bn_act(y, _bn(state_dict, f'{p}.bn1'), bn_eps, None, True)
+            y = aq(bn_act(y, _bn(state_dict, f'{p}.bn1'), bn_eps, None, True))
             outids2, pairs2, num2, _ = rulebook(spec, idx, shape)  # rebuilt: no indice_key
-            w2 = weight_to_kio(state_dict[f'{p}.conv2.weight'], 3, spec['cout'], spec['cout'])
+            w2 = wq(weight_to_kio(state_dict[f'{p}.conv2.weight'], 3, spec['cout'], spec['cout']))
             y = indice_conv(y, w2, pairs2, num2, outids2.shape[0], True)
-            y = bn_act(y, _bn(state_dict, f'{p}.bn2'), bn_eps, identity, True)
+            y = aq(bn_act(y, _bn(state_dict, f'{p}.bn2'), bn_eps, identity, True))
             if trace is not None:
                 trace[p] = dict(in_indices=idx, in_shape=list(shape), outids=outids,
                                 out_shape=list(oshape), pairs=pairs, num=num, features=y)

@@ -44,6 +44,11 @@ SIGNATURES = {
     'sf_pack_filters_f32': (_i, [_vp, _i, _i, _i, _vp, _vp]),
     'sf_sparse_conv_f32': (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp,
                                 _i, _vp]),
+    'sf_conv_padded_cin_bf16': (_i, [_i]),
+    'sf_pack_filters_bf16': (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    'sf_cast_f32_bf16': (_i, [_vp, _i, _vp, _i, _vp, _i, _vp]),
+    'sf_sparse_conv_bf16': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp,
+                                 _i, _vp, _i, _vp]),
     'sf_dense_bev': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'sf_pad_channels_f32': (_i, [_vp, _i, _vp, _i, _vp, _i, _vp]),
     'sf_coors_max': (_i, [_vp, _i, _i, _vp, _vp]),

@@ -25,7 +25,7 @@ from .sparse_encoder import SparseEncoder
 
 class _Layer:
     __slots__ = ('conv', 'bn', 'relu', 'residual_from', 'rb', 'cin', 'cout', 'packed', 'scale',
-                 'shift', 'in_buf', 'out_buf')
+                 'shift', 'in_buf', 'out_buf', 'bf16', 'out_dtype')
 
 
 def _flatten_encoder(enc):
@@ -56,8 +56,14 @@ def _flatten_encoder(enc):
 class LidarBackbone:
 
     def __init__(self, voxel_layer_cfg, encoder, device, max_points, batch_size=1,
-                 materialize_voxels=True, training=False, overlap=True):
+                 materialize_voxels=True, training=False, overlap=True, dtype='f32'):
+        """dtype 'f32': every layer on the exact-fp32 kernels.  'bf16' (BASELINE configs[2]): the
+        first layer stays fp32 (raw metric coordinates need more than 8 significant bits), its
+        output is cast to bf16, every later layer runs on the bf16 matrix cores with fp32
+        accumulation and the last one writes fp32 for the dense map."""
         assert isinstance(encoder, SparseEncoder)
+        assert dtype in ('f32', 'bf16')
+        self.dtype = dtype
         L = self.L = _lib.lib()
         self.dev = torch.device(device)
         self.B = int(batch_size)
@@ -120,8 +126,12 @@ class LidarBackbone:
             lay = _Layer()
             lay.conv, lay.bn, lay.relu, lay.residual_from = conv, bn, relu, res
             lay.rb, lay.cin, lay.cout = rb, conv.in_channels, conv.out_channels
+            lay.bf16 = dtype == 'bf16' and len(self.layers) > 0
+            lay.out_dtype = torch.bfloat16 if lay.bf16 else torch.float32
             self.layers.append(lay)
             cur = rb['dst']
+        if dtype == 'bf16' and len(self.layers) > 1:
+            self.layers[-1].out_dtype = torch.float32
         self.out_set = cur
         self.out_channels = self.layers[-1].cout
 
@@ -134,7 +144,7 @@ class LidarBackbone:
             s['keys'] = i32(s['cap'])
             s['vals'] = i32(s['cap'])
         for rb in self.rulebooks:
-            nb = self.sets[rb['dst']]['bound']
+            nb = spconv.nbr_stride(self.sets[rb['dst']]['bound'])
             rb['nbr'] = i32(rb['K'], nb)
             rb['stride'] = nb
         ws = 0
@@ -155,8 +165,15 @@ class LidarBackbone:
         self.fbufs = {}
         for lay in self.layers:
             d = lay.rb['dst']
-            self.fbufs.setdefault((d, lay.cout), [f32(self.sets[d]['bound'], lay.cout)
-                                                  for _ in range(3)])
+            self.fbufs.setdefault((d, lay.cout, lay.out_dtype),
+                                  [torch.empty((self.sets[d]['bound'], lay.cout),
+                                               dtype=lay.out_dtype, device=dev) for _ in range(3)])
+        self.cast0 = None
+        if dtype == 'bf16' and len(self.layers) > 1:     # bf16 copy of the first layer's output
+            l0 = self.layers[0]
+            self.cast0 = torch.empty((self.sets[l0.rb['dst']]['bound'],
+                                      L.sf_conv_padded_cin_bf16(l0.cout)), dtype=torch.bfloat16,
+                                     device=dev)
         D, H, W = self.sets[self.out_set]['shape']
         self.bev = f32(self.B, self.out_channels * D, H, W)
         self.refresh_weights()
@@ -167,7 +184,7 @@ class LidarBackbone:
         for lay in self.layers:
             if lay.bn.training:
                 raise RuntimeError('LidarBackbone needs eval-mode BatchNorm (call encoder.eval())')
-            lay.packed = lay.conv.packed_filters()
+            lay.packed = lay.conv.packed_filters(torch.bfloat16 if lay.bf16 else torch.float32)
             lay.scale, lay.shift = spconv.fold_bn(lay.bn)
             if lay.conv.bias is not None:
                 lay.shift = (lay.shift + lay.conv.bias.detach().float() * lay.scale).contiguous()
@@ -186,6 +203,8 @@ class LidarBackbone:
         for bufs in self.fbufs.values():
             yield from bufs
         yield from (self.rb_ws, self.vox_ws, self.mean, self.num_points, self.bev)
+        if self.cast0 is not None:
+            yield self.cast0
         if self.voxels is not None:
             yield self.voxels
 
@@ -273,9 +292,9 @@ class LidarBackbone:
             _lib.ptr(voxel_features)
             x = voxel_features
         block_in = None
-        for lay in self.layers:
+        for li, lay in enumerate(self.layers):
             rb = lay.rb
-            bufs = self.fbufs[(rb['dst'], lay.cout)]
+            bufs = self.fbufs[(rb['dst'], lay.cout, lay.out_dtype)]
             busy = {x.data_ptr()}
             if block_in is not None:
                 busy.add(block_in.data_ptr())
@@ -285,21 +304,35 @@ class LidarBackbone:
                 block_in = x
             elif lay.residual_from == 'add':
                 residual = block_in
-            cp = L.sf_conv_padded_cin(lay.cin)
+            cp = (L.sf_conv_padded_cin_bf16 if lay.bf16 else L.sf_conv_padded_cin)(lay.cin)
             assert cp == x_ch, (cp, x_ch)
             ri = self.rulebooks.index(rb)
             if ri in rb_ready and ri not in waited:
                 main.wait_event(rb_ready[ri])
                 waited.add(ri)
-            chk(L.sf_sparse_conv_f32(
-                x.data_ptr(), cp, rb['nbr'].data_ptr(), rb['stride'], rb['K'],
-                (rb['K'] - 1) // 2 if rb['subm'] else -1, lay.packed.data_ptr(), lay.cout,
-                lay.scale.data_ptr(), lay.shift.data_ptr(),
-                residual.data_ptr() if residual is not None else None, 1 if lay.relu else 0,
-                out.data_ptr(), c0 + 4 * rb['dst'], self.sets[rb['dst']]['bound'], st))
+            k_first = (rb['K'] - 1) // 2 if rb['subm'] else -1
+            res_ptr = residual.data_ptr() if residual is not None else None
+            if lay.bf16:
+                chk(L.sf_sparse_conv_bf16(
+                    x.data_ptr(), x.shape[0], cp, rb['nbr'].data_ptr(), rb['stride'], rb['K'],
+                    k_first, lay.packed.data_ptr(), lay.cout, lay.scale.data_ptr(),
+                    lay.shift.data_ptr(), res_ptr, 1 if lay.relu else 0, out.data_ptr(),
+                    1 if lay.out_dtype == torch.float32 else 0, c0 + 4 * rb['dst'],
+                    self.sets[rb['dst']]['bound'], st))
+            else:
+                chk(L.sf_sparse_conv_f32(
+                    x.data_ptr(), cp, rb['nbr'].data_ptr(), rb['stride'], rb['K'], k_first,
+                    lay.packed.data_ptr(), lay.cout, lay.scale.data_ptr(), lay.shift.data_ptr(),
+                    res_ptr, 1 if lay.relu else 0, out.data_ptr(), c0 + 4 * rb['dst'],
+                    self.sets[rb['dst']]['bound'], st))
             if residual is not None:
                 block_in = None
             x, x_ch = out, lay.cout
+            if li == 0 and self.cast0 is not None:
+                chk(L.sf_cast_f32_bf16(out.data_ptr(), lay.cout, self.cast0.data_ptr(),
+                                       self.cast0.shape[1], c0 + 4 * rb['dst'],
+                                       self.sets[rb['dst']]['bound'], st))
+                x, x_ch = self.cast0, self.cast0.shape[1]
         # ---- dense BEV ---------------------------------------------------------------------
         o = self.sets[self.out_set]
         D, H, W = o['shape']

@@ -3,6 +3,7 @@
 Same constructor arguments, module tree and state-dict keys; forward returns the
 dense BEV map (N, C*D, H, W).
 """
+import torch
 from torch import nn
 
 from . import spconv
@@ -54,11 +55,18 @@ class SparseEncoder(nn.Module):
         coors = coors.int()
         x = spconv.SparseConvTensor(voxel_features, coors, self.sparse_shape, batch_size)
         x = self.conv_input(x)
+        if self.fp16_enabled:
+            # the reference's auto_fp16 casts voxel_features to half before conv_input
+            # (sparse_encoder.py:95); here the first layer stays fp32 (raw metric coordinates do
+            # not survive 8 significant bits) and its OUTPUT is cast: every later layer runs on the
+            # bf16 matrix cores, the last one writes fp32 for the dense map
+            x = x.replace_feature(spconv.cast_bf16(x.features))
         encode_features = []
         for encoder_layer in self.encoder_layers:
             x = encoder_layer(x)
             encode_features.append(x)
-        out = self.conv_out(encode_features[-1])
+        out = self.conv_out(encode_features[-1],
+                            out_dtype=torch.float32 if self.fp16_enabled else None)
         spatial_features = out.dense()
         N, C, D, H, W = spatial_features.shape
         return spatial_features.view(N, C * D, H, W)

@@ -102,6 +102,14 @@ class Rulebook:
         return self._pairs
 
 
+def nbr_stride(rows):
+    """Column stride (in rows) of a neighbour table for `rows` output rows: a multiple of 1024
+    rows plus 64, so that the K columns a tile reads together start 256 bytes apart modulo 4 KiB
+    and spread over the memory channels (a stride that is a multiple of 4 KiB puts all 27 on
+    one: measured 2.4x slower narrow layers at batch 8)."""
+    return (max(int(rows), 1) + 1023) // 1024 * 1024 + 64
+
+
 def build_rulebook(coords, ksize, stride, padding, dilation, subm):
     """Rulebook of one conv over `coords` (ops.get_indice_pairs semantics, spconv_ops.h:27-141)."""
     L = _lib.lib()
@@ -146,7 +154,7 @@ def build_rulebook(coords, ksize, stride, padding, dilation, subm):
             raise RuntimeError('sparse conv output set overflowed its table')
         out_coords = CoordSet(outids[:n_out], out_shape, coords.batch_size, (okeys, ovals, ocap))
     n_out = out_coords.n
-    stride_rows = max(n_out, 1)
+    stride_rows = nbr_stride(n_out)
     nbr = torch.empty((K, stride_rows), dtype=torch.int32, device=dev)
     _lib.check(L.sf_neighbor_table(_lib.ptr(out_coords.indices), None, n_out, coords.batch_size,
                                    _lib.i3(coords.spatial_shape), _lib.i3(ks), _lib.i3(st),
@@ -264,6 +272,42 @@ def pack_filters(weight_kio):
     return packed
 
 
+def pack_filters_bf16(weight_kio):
+    """(K, Cin, Cout) fp32 on the device -> bf16 MFMA fragment order for sf_sparse_conv_bf16."""
+    L = _lib.lib()
+    K, cin, cout = weight_kio.shape
+    cp = L.sf_conv_padded_cin_bf16(cin)
+    if cp < 0:
+        raise RuntimeError(f'unsupported in_channels {cin}')
+    packed = torch.empty(K * cp * cout, dtype=torch.bfloat16, device=weight_kio.device)
+    _lib.check(L.sf_pack_filters_bf16(_lib.ptr(weight_kio.contiguous()), K, cin, cout,
+                                      packed.data_ptr(), _lib.stream(weight_kio.device)))
+    return packed
+
+
+def cast_bf16(features, channels=None):
+    """(N, C) fp32 -> (N, channels >= C) bf16, round to nearest even, extra columns zero: the
+    explicit form of auto_fp16's cast of voxel_features (sparse_encoder.py:95)."""
+    _lib.require(features, torch.float32, 'features')
+    n, c = features.shape
+    cd = c if channels is None else int(channels)
+    out = torch.empty((n, cd), dtype=torch.bfloat16, device=features.device)
+    _lib.check(_lib.lib().sf_cast_f32_bf16(_lib.ptr(features.contiguous()), c, out.data_ptr(), cd,
+                                           None, n, _lib.stream(features.device)))
+    return out
+
+
+def _padded_features_bf16(features, cin):
+    cp = _lib.lib().sf_conv_padded_cin_bf16(cin)
+    if cp < 0:
+        raise RuntimeError(f'unsupported in_channels {cin}')
+    if features.shape[1] == cp:
+        return features.contiguous(), cp
+    dst = torch.zeros((features.shape[0], cp), dtype=torch.bfloat16, device=features.device)
+    dst[:, :features.shape[1]] = features
+    return dst, cp
+
+
 def _padded_features(features, cin):
     L = _lib.lib()
     cp = L.sf_conv_padded_cin(cin)
@@ -279,12 +323,34 @@ def _padded_features(features, cin):
 
 
 def sparse_conv(features, packed_filters, cin, cout, rulebook, scale=None, shift=None,
-                residual=None, relu=False):
-    """One fused layer: conv (+ folded BN scale/shift) (+ residual) (+ ReLU)."""
+                residual=None, relu=False, out_dtype=None):
+    """One fused layer: conv (+ folded BN scale/shift) (+ residual) (+ ReLU).  fp32 features run
+    the exact-fp32 kernel; bf16 features (with bf16-packed filters) the bf16 MFMA kernel, whose
+    output is bf16 unless out_dtype=torch.float32."""
     L = _lib.lib()
-    _lib.require(features, torch.float32, 'features')
     if features.shape[0] != rulebook.in_coords.n:
         raise RuntimeError('features rows do not match the rulebook input set')
+    if features.dtype == torch.bfloat16:
+        _lib.require(packed_filters, torch.bfloat16, 'packed filters')
+        x, cp = _padded_features_bf16(features, cin)
+        n_out = rulebook.out_coords.n
+        odt = torch.bfloat16 if out_dtype is None else out_dtype
+        if odt not in (torch.bfloat16, torch.float32):
+            raise RuntimeError(f'unsupported out_dtype {odt}')
+        out = torch.empty((n_out, cout), dtype=odt, device=features.device)
+        if residual is not None:
+            if residual.shape != out.shape:
+                raise RuntimeError('residual shape mismatch')
+            residual = _lib.require(residual, torch.bfloat16, 'residual').contiguous()
+        _lib.check(L.sf_sparse_conv_bf16(
+            _lib.ptr(x), x.shape[0], cp, rulebook.nbr.data_ptr(), rulebook.nbr.shape[1], rulebook.K,
+            rulebook.k_first, _lib.ptr(packed_filters), cout, _lib.ptr(scale), _lib.ptr(shift),
+            _lib.ptr(residual), 1 if relu else 0, out.data_ptr(), 1 if odt == torch.float32 else 0,
+            None, n_out, _lib.stream(features.device)))
+        return out
+    _lib.require(features, torch.float32, 'features')
+    if out_dtype not in (None, torch.float32):
+        raise RuntimeError('fp32 features give fp32 output (cast with cast_bf16)')
     x, cp = _padded_features(features, cin)
     n_out = rulebook.out_coords.n
     out = torch.empty((n_out, cout), dtype=torch.float32, device=features.device)
@@ -381,8 +447,7 @@ class SparseConvolution(SparseModule):
             self.bias = nn.Parameter(torch.empty(out_channels))
         else:
             self.register_parameter('bias', None)
-        self._packed = None
-        self._packed_key = None
+        self._packed = {}
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -400,15 +465,16 @@ class SparseConvolution(SparseModule):
             state_dict[prefix + 'weight'] = w.permute(4, 0, 1, 2, 3).contiguous()
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
-    def packed_filters(self):
+    def packed_filters(self, dtype=torch.float32):
         key = (self.weight._version, self.weight.device, self.weight.data_ptr())
-        if self._packed is None or self._packed_key != key:
+        hit = self._packed.get(dtype)
+        if hit is None or hit[0] != key:
             K = int(np.prod(self.kernel_size))
             w = self.weight.detach().float().permute(1, 2, 3, 4, 0).reshape(
                 K, self.in_channels, self.out_channels).contiguous()
-            self._packed = pack_filters(w)
-            self._packed_key = key
-        return self._packed
+            hit = (key, pack_filters_bf16(w) if dtype == torch.bfloat16 else pack_filters(w))
+            self._packed[dtype] = hit
+        return hit[1]
 
     def rulebook_for(self, input):
         datas = input.find_indice_pair(self.indice_key)
@@ -420,7 +486,8 @@ class SparseConvolution(SparseModule):
             input.indice_dict[self.indice_key] = IndiceData(rb)
         return rb
 
-    def forward_fused(self, input, scale=None, shift=None, residual=None, relu=False):
+    def forward_fused(self, input, scale=None, shift=None, residual=None, relu=False,
+                      out_dtype=None):
         assert isinstance(input, SparseConvTensor)
         rb = self.rulebook_for(input)
         if self.bias is not None:
@@ -428,8 +495,9 @@ class SparseConvolution(SparseModule):
             shift = b if shift is None else shift + b * scale
             if scale is None:
                 scale = torch.ones_like(b)
-        feats = sparse_conv(input.features, self.packed_filters(), self.in_channels,
-                            self.out_channels, rb, scale, shift, residual, relu)
+        feats = sparse_conv(input.features, self.packed_filters(input.features.dtype),
+                            self.in_channels, self.out_channels, rb, scale, shift, residual, relu,
+                            out_dtype)
         out = SparseConvTensor(feats, rb.out_coords.indices, rb.out_coords.spatial_shape,
                                input.batch_size, input.grid)
         out.indice_dict = input.indice_dict
@@ -493,7 +561,9 @@ class SparseSequential(SparseModule):
                 raise KeyError('name exists')
         self.add_module(name, module)
 
-    def forward(self, input):
+    def forward(self, input, out_dtype=None):
+        """out_dtype: dtype of the features a fused conv -> BN [-> ReLU] run that ENDS the sequence
+        writes (bf16 inputs only; SparseEncoder asks its last layer for fp32)."""
         mods = list(self._modules.values())
         i = 0
         while i < len(mods):
@@ -502,7 +572,9 @@ class SparseSequential(SparseModule):
                     i + 1 < len(mods) and _bn_foldable(mods[i + 1]):
                 scale, shift = fold_bn(mods[i + 1])
                 relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
-                input = m.forward_fused(input, scale, shift, None, relu)
+                last = i + (3 if relu else 2) >= len(mods)
+                input = m.forward_fused(input, scale, shift, None, relu,
+                                        out_dtype if last else None)
                 i += 3 if relu else 2
             elif isinstance(m, SparseModule):
                 assert isinstance(input, SparseConvTensor)
