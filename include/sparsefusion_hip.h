@@ -130,6 +130,23 @@ SF_API int sf_conv_output_set(const int *indices, const int *n_dev, int n_bound,
                               int *overflow_dev, void *workspace, size_t workspace_bytes,
                               void *stream);
 
+/* Bytes of scratch sf_strided_rulebook needs. */
+SF_API size_t sf_strided_rulebook_workspace(int n_bound, int out_capacity, const int ksize[3],
+                                            const int stride[3]);
+
+/* sf_conv_output_set and sf_neighbor_table of a strided SparseConv3d in one call (same
+ * reference functions: getIndicePairsConv, geometry.h:144-194), built from the INPUT side: every
+ * input remembers the output-table slots it touched, so the table is probed once per pair instead
+ * of once per (output row, kernel offset) -- most of which miss at stride 2.  Results are
+ * identical to the two separate calls (same output row order, same table; for duplicate input
+ * coordinates the first occurrence wins).  nbr is (K, nbr_stride) with nbr_stride >= outids_rows. */
+SF_API int sf_strided_rulebook(const int *indices, const int *n_dev, int n_bound, int batch,
+                               const int out_shape[3], const int ksize[3], const int stride[3],
+                               const int padding[3], uint32_t *out_keys, int *out_vals,
+                               int out_capacity, int *outids, int outids_rows, int *n_out_dev,
+                               int *overflow_dev, int *nbr, int nbr_stride, void *workspace,
+                               size_t workspace_bytes, void *stream);
+
 /* Neighbour table = the rulebook in output-major form: nbr[k*nbr_stride + o] is the input row
  * that feeds output row o through kernel offset k = (kz*kH+ky)*kW+kx, or -1.  Same pairs as
  * indicePairs/indiceNum of getIndicePairsSubM / getIndicePairsConv (geometry.h:247-297,

@@ -35,6 +35,9 @@ SIGNATURES = {
     'sf_conv_output_set_workspace': (_sz, [_i, _i]),
     'sf_conv_output_set': (_i, [_vp, _vp, _i, _i, _i3, _i3, _i3, _i3, _vp, _vp, _i, _vp, _i, _vp,
                                 _vp, _vp, _sz, _vp]),
+    'sf_strided_rulebook_workspace': (_sz, [_i, _i, _i3, _i3]),
+    'sf_strided_rulebook': (_i, [_vp, _vp, _i, _i, _i3, _i3, _i3, _i3, _vp, _vp, _i, _vp, _i, _vp,
+                                 _vp, _vp, _i, _vp, _sz, _vp]),
     'sf_neighbor_table': (_i, [_vp, _vp, _i, _i, _i3, _i3, _i3, _i3, _vp, _vp, _i, _i, _vp, _i,
                                _vp]),
     'sf_export_indice_pairs_workspace': (_sz, [_i, _i]),

@@ -202,6 +202,291 @@ __global__ void neighbor_table_kernel(const int *__restrict__ outids, const int 
   }
 }
 
+// ---- fast paths ------------------------------------------------------------------------
+// The lookups above are latency bound (one dependent L2 round trip per probe).  The two kernels
+// below cut the number of probes instead of trying to speed each one up.
+
+// columns [k0, k1) of the table := -1 for the rows in use
+__global__ void nbr_fill_kernel(int *__restrict__ nbr, int nbr_stride, int k0, int k1,
+                                const int *n_dev, int n_bound) {
+  const int n = load_n(n_dev, n_bound);
+  const int k = k0 + blockIdx.y;
+  if (k >= k1) return;
+  int *__restrict__ col = nbr + (size_t)k * nbr_stride;
+  for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < n; o += gridDim.x * blockDim.x) col[o] = -1;
+}
+
+// SubMConv3d 3x3x3: if row o finds row i under offset k, then row i finds row o under offset
+// 26-k.  Each row probes the 13 offsets below the centre only (all 13 first probes in flight at
+// once), writes its own entry and scatters the mirrored one (columns 14..26 are pre-filled with
+// -1; atomicMin on the unsigned view keeps the first occurrence among duplicate coordinates).
+__global__ void __launch_bounds__(kThreads)
+subm27_table_kernel(const int *__restrict__ outids, const int *n_dev, int n_bound, Geo g, int batch,
+                    const uint32_t *__restrict__ keys, const int *__restrict__ vals, uint32_t mask,
+                    int *__restrict__ nbr, int nbr_stride) {
+  const int n = load_n(n_dev, n_bound);
+  for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < n; o += gridDim.x * blockDim.x) {
+    const int4 c = reinterpret_cast<const int4 *>(outids)[o];
+    nbr[(size_t)13 * nbr_stride + o] = o;  // centre: every row pairs with itself
+    const bool okb = c.x >= 0 && c.x < batch;
+    uint32_t key[13], slot[13], kc[13];
+    int vc[13];
+    bool ok[13];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {
+      const int iz = c.y + k / 9 - 1, iy = c.z + (k / 3) % 3 - 1, ix = c.w + k % 3 - 1;
+      ok[k] = okb && iz >= 0 && iz < g.ishape[0] && iy >= 0 && iy < g.ishape[1] && ix >= 0 &&
+              ix < g.ishape[2];
+      key[k] = lin_key(c.x, iz, iy, ix, g.ishape);
+      slot[k] = ok[k] ? sf_first_slot(key[k], mask) : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {  // 26 independent loads in flight
+      kc[k] = keys[slot[k]];
+      vc[k] = vals[slot[k]];
+    }
+    // resolve in rounds: every offset that still needs a probe issues it together with the
+    // others (one memory round trip per round, not per offset)
+    int res[13];
+    bool pend[13];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {
+      res[k] = -1;
+      pend[k] = ok[k];
+    }
+    for (uint32_t round = 0; round <= mask; ++round) {
+      bool more = false;
+#pragma unroll
+      for (int k = 0; k < 13; ++k) {
+        if (pend[k]) {
+          if (kc[k] == key[k]) {
+            res[k] = vc[k];
+            pend[k] = false;
+          } else if (kc[k] == SF_EMPTY_KEY) {
+            pend[k] = false;
+          } else {
+            slot[k] = (slot[k] + 1) & mask;
+            more = true;
+          }
+        }
+      }
+      if (!more) break;
+#pragma unroll
+      for (int k = 0; k < 13; ++k) {
+        if (pend[k]) {
+          kc[k] = keys[slot[k]];
+          vc[k] = vals[slot[k]];
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {
+      nbr[(size_t)k * nbr_stride + o] = res[k];
+      if (res[k] >= 0 && res[k] < n)
+        atomicMin(reinterpret_cast<unsigned *>(nbr) + (size_t)(26 - k) * nbr_stride + res[k],
+                  (unsigned)o);
+    }
+  }
+}
+
+// Strided rulebook, input side.  Every input remembers the table slots of the outputs it reaches
+// (slots[e*n_bound + j], e = ordinal in for_each_output order), so the output table is probed
+// ONCE per (input, output) -- the count / assign passes and the neighbour table reuse the slots.
+__global__ void outset_insert_slots_kernel(const int *__restrict__ indices, const int *n_dev,
+                                           int n_bound, Geo g, uint32_t *__restrict__ keys,
+                                           uint32_t mask, int *__restrict__ first,
+                                           int *__restrict__ slots, int *overflow_dev) {
+  const int n = load_n(n_dev, n_bound);
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    int4 c = reinterpret_cast<const int4 *>(indices)[j];
+    int e = 0;
+    for_each_output(c, g, [&](int k, int oz, int oy, int ox) {
+      int slot = sf_hash_insert(keys, mask, lin_key(c.x, oz, oy, ox, g.oshape));
+      if (slot < 0) {
+        if (overflow_dev) *overflow_dev = 1;
+      } else {
+        atomicMin(&first[slot], j * g.K + k);
+      }
+      slots[(size_t)e * n_bound + j] = slot;
+      ++e;
+    });
+  }
+}
+
+__global__ void __launch_bounds__(kThreads)
+outset_count_slots_kernel(const int *__restrict__ indices, const int *n_dev, int n_bound, Geo g,
+                          const int *__restrict__ first, const int *__restrict__ slots,
+                          int *__restrict__ bsum, unsigned *__restrict__ ftmask) {
+  __shared__ int smem[17];
+  const int n = load_n(n_dev, n_bound);
+  if (blockIdx.x * kChunk >= n) return;
+  int c = 0;
+  const int j = blockIdx.x * kChunk + threadIdx.x;
+  if (j < n) {
+    int4 ci = reinterpret_cast<const int4 *>(indices)[j];
+    unsigned fm = 0;
+    int e = 0;
+    for_each_output(ci, g, [&](int k, int, int, int) {
+      const int slot = slots[(size_t)e * n_bound + j];
+      ++e;
+      if (slot >= 0 && first[slot] == j * g.K + k) {
+        ++c;
+        fm |= 1u << k;
+      }
+    });
+    ftmask[j] = fm;
+  }
+  int total = sf_block_sum(c, smem);
+  if (threadIdx.x == 0) bsum[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(kThreads)
+outset_assign_slots_kernel(const int *__restrict__ indices, const int *n_dev, int n_bound, Geo g,
+                           const int *__restrict__ slots, const unsigned *__restrict__ ftmask,
+                           const int *__restrict__ bsum, int nblk, int *__restrict__ vals,
+                           int *__restrict__ outids, int outids_rows, int *__restrict__ n_out_dev,
+                           int *overflow_dev) {
+  __shared__ int smem[17];
+  const int n = load_n(n_dev, n_bound);
+  if (blockIdx.x > 0 && blockIdx.x * kChunk >= n) return;
+  const int nblk_used = (n + kChunk - 1) / kChunk;
+  int before, all;
+  sf_block_prefix_of(bsum, nblk_used < nblk ? nblk_used : nblk, blockIdx.x, smem, &before, &all);
+  const int j = blockIdx.x * kChunk + threadIdx.x;
+  const unsigned fm = j < n ? ftmask[j] : 0u;
+  int total;
+  int row = before + sf_block_excl_scan(__popc(fm), smem, &total);
+  if (fm != 0) {
+    int4 ci = reinterpret_cast<const int4 *>(indices)[j];
+    int e = 0;
+    for_each_output(ci, g, [&](int k, int oz, int oy, int ox) {
+      const int slot = slots[(size_t)e * n_bound + j];
+      ++e;
+      if (((fm >> k) & 1u) && slot >= 0) {
+        if (row < outids_rows) {
+          vals[slot] = row;
+          reinterpret_cast<int4 *>(outids)[row] = make_int4(ci.x, oz, oy, ox);
+        } else {
+          vals[slot] = -1;
+          if (overflow_dev) *overflow_dev = 1;
+        }
+        ++row;
+      }
+    });
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *n_out_dev = all < outids_rows ? all : outids_rows;
+}
+
+// nbr[k][output row] = input row, scattered from the input side (the table is pre-filled with
+// -1; atomicMin on the unsigned view: first occurrence wins among duplicate input coordinates)
+__global__ void outset_scatter_table_kernel(const int *__restrict__ indices, const int *n_dev,
+                                            int n_bound, Geo g, const int *__restrict__ slots,
+                                            const int *__restrict__ vals, int *__restrict__ nbr,
+                                            int nbr_stride, int nbr_rows) {
+  const int n = load_n(n_dev, n_bound);
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    int4 c = reinterpret_cast<const int4 *>(indices)[j];
+    int e = 0;
+    for_each_output(c, g, [&](int k, int, int, int) {
+      const int slot = slots[(size_t)e * n_bound + j];
+      ++e;
+      if (slot < 0) return;
+      const int orow = vals[slot];
+      if (orow >= 0 && orow < nbr_rows)
+        atomicMin(reinterpret_cast<unsigned *>(nbr) + (size_t)k * nbr_stride + orow, (unsigned)j);
+    });
+  }
+}
+
+// Kernel extents <= 3 per dimension (every conv of SparseEncoder): the <= 27 (offset, output)
+// candidates of one input are enumerated branch-free into registers, so that the table accesses
+// of ALL of them are in flight together.  Order = ascending offset index = for_each_output order;
+// ord[ci] is the candidate's ordinal among the valid ones (its row in the slots array).
+__device__ __forceinline__ void enumerate27(const int4 c, const Geo &g, bool (&ok)[27],
+                                            int (&kidx)[27], uint32_t (&key)[27], int (&ord)[27]) {
+  bool v[3][3];
+  int od[3][3];
+  const int in[3] = {c.y, c.z, c.w};
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) {
+      const int t = in[d] + g.pad[d] - kd;
+      const int o = t / g.st[d];
+      v[d][kd] = kd < g.ks[d] && t >= 0 && o * g.st[d] == t && o < g.oshape[d];
+      od[d][kd] = o;
+    }
+  int e = 0;
+#pragma unroll
+  for (int k0 = 0; k0 < 3; ++k0)
+#pragma unroll
+    for (int k1 = 0; k1 < 3; ++k1)
+#pragma unroll
+      for (int k2 = 0; k2 < 3; ++k2) {
+        const int ci = (k0 * 3 + k1) * 3 + k2;
+        ok[ci] = v[0][k0] && v[1][k1] && v[2][k2];
+        kidx[ci] = (k0 * g.ks[1] + k1) * g.ks[2] + k2;
+        key[ci] = lin_key(c.x, od[0][k0], od[1][k1], od[2][k2], g.oshape);
+        ord[ci] = e;
+        e += ok[ci] ? 1 : 0;
+      }
+}
+
+__global__ void __launch_bounds__(kThreads)
+outset_count27_kernel(const int *__restrict__ indices, const int *n_dev, int n_bound, Geo g,
+                      const int *__restrict__ first, const int *__restrict__ slots,
+                      int *__restrict__ bsum, unsigned *__restrict__ ftmask) {
+  __shared__ int smem[17];
+  const int n = load_n(n_dev, n_bound);
+  if (blockIdx.x * kChunk >= n) return;
+  int c = 0;
+  const int j = blockIdx.x * kChunk + threadIdx.x;
+  if (j < n) {
+    const int4 ci = reinterpret_cast<const int4 *>(indices)[j];
+    bool ok[27];
+    int kidx[27], ord[27], sl[27], fv[27];
+    uint32_t key[27];
+    enumerate27(ci, g, ok, kidx, key, ord);
+#pragma unroll
+    for (int i = 0; i < 27; ++i) sl[i] = ok[i] ? slots[(size_t)ord[i] * n_bound + j] : -1;
+#pragma unroll
+    for (int i = 0; i < 27; ++i) fv[i] = sl[i] >= 0 ? first[sl[i]] : -1;
+    unsigned fm = 0;
+#pragma unroll
+    for (int i = 0; i < 27; ++i)
+      if (sl[i] >= 0 && fv[i] == j * g.K + kidx[i]) {
+        ++c;
+        fm |= 1u << kidx[i];
+      }
+    ftmask[j] = fm;
+  }
+  int total = sf_block_sum(c, smem);
+  if (threadIdx.x == 0) bsum[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(kThreads)
+outset_scatter27_kernel(const int *__restrict__ indices, const int *n_dev, int n_bound, Geo g,
+                        const int *__restrict__ slots, const int *__restrict__ vals,
+                        int *__restrict__ nbr, int nbr_stride, int nbr_rows) {
+  const int n = load_n(n_dev, n_bound);
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    const int4 c = reinterpret_cast<const int4 *>(indices)[j];
+    bool ok[27];
+    int kidx[27], ord[27], sl[27], orow[27];
+    uint32_t key[27];
+    enumerate27(c, g, ok, kidx, key, ord);
+#pragma unroll
+    for (int i = 0; i < 27; ++i) sl[i] = ok[i] ? slots[(size_t)ord[i] * n_bound + j] : -1;
+#pragma unroll
+    for (int i = 0; i < 27; ++i) orow[i] = sl[i] >= 0 ? vals[sl[i]] : -1;
+#pragma unroll
+    for (int i = 0; i < 27; ++i)
+      if (orow[i] >= 0 && orow[i] < nbr_rows)
+        atomicMin(reinterpret_cast<unsigned *>(nbr) + (size_t)kidx[i] * nbr_stride + orow[i],
+                  (unsigned)j);
+  }
+}
+
 // ---- export to the reference's (K,2,L) pair lists ------------------------------------
 __global__ void fill_int_kernel(int *__restrict__ p, long long n, int v) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -392,6 +677,91 @@ extern "C" int sf_conv_output_set(const int *indices, const int *n_dev, int n_bo
   return SF_OK;
 }
 
+static int conv_reach(const int ks[3], const int st[3]) {
+  int r = 1;
+  for (int i = 0; i < 3; ++i) r *= (ks[i] + st[i] - 1) / st[i];
+  return r;
+}
+
+extern "C" size_t sf_strided_rulebook_workspace(int n_bound, int out_capacity, const int ksize[3],
+                                                const int stride[3]) {
+  if (n_bound < 0 || out_capacity < 0 || !ksize || !stride) return 0;
+  for (int i = 0; i < 3; ++i)
+    if (ksize[i] < 1 || stride[i] < 1) return 0;
+  const size_t nb = (size_t)(n_bound > 0 ? n_bound : 1);
+  return sf_conv_output_set_workspace(n_bound, out_capacity) +
+         align_up(nb * 4 * (size_t)conv_reach(ksize, stride));
+}
+
+extern "C" int sf_strided_rulebook(const int *indices, const int *n_dev, int n_bound, int batch,
+                                   const int out_shape[3], const int ksize[3], const int stride[3],
+                                   const int padding[3], uint32_t *out_keys, int *out_vals,
+                                   int out_capacity, int *outids, int outids_rows, int *n_out_dev,
+                                   int *overflow_dev, int *nbr, int nbr_stride, void *workspace,
+                                   size_t workspace_bytes, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  SF_CHECK_ARG(n_bound >= 0 && batch >= 1 && out_shape, "bad n_bound/batch/out_shape");
+  SF_CHECK_ARG(out_keys && out_vals && is_pow2(out_capacity), "output table NULL or capacity %d "
+               "not a power of two", out_capacity);
+  SF_CHECK_ARG(outids && outids_rows >= 0 && n_out_dev, "outids / n_out_dev is NULL");
+  SF_CHECK_ARG(nbr && nbr_stride >= outids_rows, "nbr NULL or nbr_stride %d < outids_rows %d",
+               nbr_stride, outids_rows);
+  SF_CHECK_ARG(n_bound == 0 || indices, "indices is NULL");
+  Geo g;
+  int rc = make_geo(nullptr, out_shape, ksize, stride, padding, batch, &g);
+  if (rc != SF_OK) return rc;
+  SF_CHECK_ARG((long long)n_bound * g.K < 0x7FFFFFFFll, "n_bound*K overflows int32");
+  const size_t need = sf_strided_rulebook_workspace(n_bound, out_capacity, ksize, stride);
+  if (!workspace || workspace_bytes < need) {
+    sf_set_error("workspace too small: %zu < %zu bytes", workspace_bytes, need);
+    return SF_ERR_WORKSPACE;
+  }
+  int *first = (int *)workspace;
+  int *bsum = (int *)((char *)workspace + align_up((size_t)out_capacity * 4));
+  const int nblk = sf_div_up(n_bound > 0 ? n_bound : 1, kChunk);
+  unsigned *ftmask = (unsigned *)((char *)bsum + align_up((size_t)nblk * 4));
+  int *slots = (int *)((char *)workspace + sf_conv_output_set_workspace(n_bound, out_capacity));
+  const uint32_t mask = (uint32_t)(out_capacity - 1);
+  hipLaunchKernelGGL(table_fill_kernel, dim3(sf_grid(out_capacity, kThreads)), dim3(kThreads), 0,
+                     st, out_keys, first, out_capacity, out_vals, out_capacity, -1);
+  SF_CHECK_LAUNCH();
+  const bool small = ksize[0] <= 3 && ksize[1] <= 3 && ksize[2] <= 3;  // batched-probe kernels
+  // (a batched-probe insert -- all candidates' reads, then all claims, in rounds -- measured
+  // SLOWER than the sequential one, 50 vs 34 us: most inserts find their key already present on
+  // the first read, and the batched form pays 27 masked steps per round)
+  hipLaunchKernelGGL(outset_insert_slots_kernel, dim3(sf_grid(n_bound, kThreads)), dim3(kThreads),
+                     0, st, indices, n_dev, n_bound, g, out_keys, mask, first, slots, overflow_dev);
+  SF_CHECK_LAUNCH();
+  if (small)
+    hipLaunchKernelGGL(outset_count27_kernel, dim3(nblk), dim3(kThreads), 0, st, indices, n_dev,
+                       n_bound, g, (const int *)first, (const int *)slots, bsum, ftmask);
+  else
+    hipLaunchKernelGGL(outset_count_slots_kernel, dim3(nblk), dim3(kThreads), 0, st, indices,
+                       n_dev, n_bound, g, (const int *)first, (const int *)slots, bsum, ftmask);
+  SF_CHECK_LAUNCH();
+  hipLaunchKernelGGL(outset_assign_slots_kernel, dim3(nblk), dim3(kThreads), 0, st, indices, n_dev,
+                     n_bound, g, (const int *)slots, (const unsigned *)ftmask, (const int *)bsum,
+                     nblk, out_vals, outids, outids_rows, n_out_dev, overflow_dev);
+  SF_CHECK_LAUNCH();
+  if (outids_rows > 0) {
+    int gx = sf_div_up(outids_rows, kThreads);
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(nbr_fill_kernel, dim3(gx, g.K), dim3(kThreads), 0, st, nbr, nbr_stride, 0,
+                       g.K, (const int *)n_out_dev, outids_rows);
+    SF_CHECK_LAUNCH();
+    if (small)
+      hipLaunchKernelGGL(outset_scatter27_kernel, dim3(sf_grid(n_bound, kThreads)), dim3(kThreads),
+                         0, st, indices, n_dev, n_bound, g, (const int *)slots,
+                         (const int *)out_vals, nbr, nbr_stride, outids_rows);
+    else
+      hipLaunchKernelGGL(outset_scatter_table_kernel, dim3(sf_grid(n_bound, kThreads)),
+                         dim3(kThreads), 0, st, indices, n_dev, n_bound, g, (const int *)slots,
+                         (const int *)out_vals, nbr, nbr_stride, outids_rows);
+    SF_CHECK_LAUNCH();
+  }
+  return SF_OK;
+}
+
 extern "C" int sf_neighbor_table(const int *outids, const int *n_out_dev, int n_out_bound,
                                  int batch, const int in_shape[3], const int ksize[3],
                                  const int stride[3], const int padding[3],
@@ -409,6 +779,20 @@ extern "C" int sf_neighbor_table(const int *outids, const int *n_out_dev, int n_
   SF_CHECK_ARG(!identity_center || (g.K % 2 == 1), "identity_center needs an odd kernel volume");
   if (n_out_bound == 0) return SF_OK;
   SF_CHECK_ARG(outids, "outids is NULL");
+  if (identity_center && g.K == 27 && ksize[0] == 3 && ksize[1] == 3 && stride[0] == 1 &&
+      stride[1] == 1 && stride[2] == 1 && padding[0] == 1 && padding[1] == 1 && padding[2] == 1) {
+    // SubMConv3d 3x3x3: half the probes, the other half mirrored (subm27_table_kernel)
+    int gx = sf_div_up(n_out_bound, kThreads);
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(nbr_fill_kernel, dim3(gx > 1024 ? 1024 : gx, 13), dim3(kThreads), 0, st, nbr,
+                       nbr_stride, 14, 27, n_out_dev, n_out_bound);
+    SF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(subm27_table_kernel, dim3(gx), dim3(kThreads), 0, st, outids, n_out_dev,
+                       n_out_bound, g, batch, in_keys, in_vals, (uint32_t)(in_capacity - 1), nbr,
+                       nbr_stride);
+    SF_CHECK_LAUNCH();
+    return SF_OK;
+  }
   // lookup chains are latency-bound: one (offset, row) per thread where the bound allows it
   int nt_x = sf_div_up(n_out_bound, kThreads);
   if (nt_x > 2048) nt_x = 2048;

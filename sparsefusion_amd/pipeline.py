@@ -150,8 +150,9 @@ class LidarBackbone:
         ws = 0
         for rb in self.rulebooks:
             if not rb['subm']:
-                ws = max(ws, L.sf_conv_output_set_workspace(self.sets[rb['src']]['bound'],
-                                                            self.sets[rb['dst']]['cap']))
+                ws = max(ws, L.sf_strided_rulebook_workspace(
+                    self.sets[rb['src']]['bound'], self.sets[rb['dst']]['cap'], _lib.i3(rb['ks']),
+                    _lib.i3(rb['st'])))
         self.rb_ws = torch.empty(max(ws, 256), dtype=torch.uint8, device=dev)
         self.rb_ws_bytes = max(ws, 256)
         vws = L.sf_hard_voxelize_workspace(self.max_points_in, self.mp)
@@ -268,11 +269,18 @@ class LidarBackbone:
             # the first rulebook feeds the very first layer: it stays on the main stream
             ss = side.cuda_stream if (fork and ri > 0) else st
             if not rb['subm']:
-                chk(L.sf_conv_output_set(
+                # output set + neighbour table from the input side (one probe per pair)
+                chk(L.sf_strided_rulebook(
                     src['indices'].data_ptr(), n_src, src['bound'], self.B, _lib.i3(dst['shape']),
                     _lib.i3(rb['ks']), _lib.i3(rb['st']), _lib.i3(rb['pd']), dst['keys'].data_ptr(),
                     dst['vals'].data_ptr(), dst['cap'], dst['indices'].data_ptr(), dst['bound'],
-                    n_dst, ovf, self.rb_ws.data_ptr(), self.rb_ws_bytes, ss))
+                    n_dst, ovf, rb['nbr'].data_ptr(), rb['stride'], self.rb_ws.data_ptr(),
+                    self.rb_ws_bytes, ss))
+                if fork and ri > 0:
+                    e = torch.cuda.Event()
+                    e.record(side)
+                    rb_ready[ri] = e
+                continue
             chk(L.sf_neighbor_table(
                 dst['indices'].data_ptr(), n_dst, dst['bound'], self.B, _lib.i3(src['shape']),
                 _lib.i3(rb['ks']), _lib.i3(rb['st']), _lib.i3(rb['pd']), src['keys'].data_ptr(),

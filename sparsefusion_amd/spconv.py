@@ -141,18 +141,27 @@ def build_rulebook(coords, ksize, stride, padding, dilation, subm):
         ovals = torch.empty(ocap, dtype=torch.int32, device=dev)
         outids = torch.empty((bound, 4), dtype=torch.int32, device=dev)
         cnt = torch.zeros(2, dtype=torch.int32, device=dev)  # [n_out, overflow]
-        wsb = L.sf_conv_output_set_workspace(coords.n, ocap)
+        wsb = L.sf_strided_rulebook_workspace(coords.n, ocap, _lib.i3(ks), _lib.i3(st))
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-        _lib.check(L.sf_conv_output_set(_lib.ptr(coords.indices), None, coords.n,
-                                        coords.batch_size, _lib.i3(out_shape), _lib.i3(ks),
-                                        _lib.i3(st), _lib.i3(pd), okeys.data_ptr(),
-                                        ovals.data_ptr(), ocap, outids.data_ptr(), bound,
-                                        cnt.data_ptr(), cnt.data_ptr() + 4, ws.data_ptr(), wsb,
-                                        stream))
-        n_out, overflow = cnt.tolist()  # the one host sync of a strided conv in module mode
+        # output set + neighbour table in one call, sized for the bound; trimmed below once the
+        # row count is known (the one host sync of a strided conv in module mode)
+        wide = torch.empty((K, nbr_stride(bound)), dtype=torch.int32, device=dev)
+        _lib.check(L.sf_strided_rulebook(_lib.ptr(coords.indices), None, coords.n,
+                                         coords.batch_size, _lib.i3(out_shape), _lib.i3(ks),
+                                         _lib.i3(st), _lib.i3(pd), okeys.data_ptr(),
+                                         ovals.data_ptr(), ocap, outids.data_ptr(), bound,
+                                         cnt.data_ptr(), cnt.data_ptr() + 4, wide.data_ptr(),
+                                         wide.shape[1], ws.data_ptr(), wsb, stream))
+        n_out, overflow = cnt.tolist()
         if overflow:
             raise RuntimeError('sparse conv output set overflowed its table')
         out_coords = CoordSet(outids[:n_out], out_shape, coords.batch_size, (okeys, ovals, ocap))
+        nbr = torch.empty((K, nbr_stride(n_out)), dtype=torch.int32, device=dev)
+        nbr[:, :n_out] = wide[:, :n_out]
+        del wide
+        rb = Rulebook(nbr, K, coords, out_coords, ks, st, pd, False)
+        coords.rulebooks[key] = rb
+        return rb
     n_out = out_coords.n
     stride_rows = nbr_stride(n_out)
     nbr = torch.empty((K, stride_rows), dtype=torch.int32, device=dev)
