@@ -50,8 +50,17 @@ def build_backbone(workload, dev, batch, max_points, overlap=True, dtype='f32'):
     enc = SparseEncoder(**ecfg)
     enc.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
     enc = enc.to(dev).eval()
+    vfe = None
+    vcfg = dict(cfg['pts_voxel_encoder'])
+    if vcfg.pop('type') == 'HardVFE':          # Waymo config: learned voxel encoder, seeded weights
+        from sparsefusion_amd.voxel_encoder import HardVFE
+        vfe = HardVFE(**vcfg)
+        vsd = synth.hard_vfe_state_dict(2025, vfe.in_channels, vcfg['feat_channels'])
+        vfe.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in vsd.items()})
+        vfe = vfe.to(dev).eval()
+        sd = dict(sd, **{'vfe.' + k: v for k, v in vsd.items()})
     bb = LidarBackbone(cfg['pts_voxel_layer'], enc, dev, max_points, batch_size=batch,
-                       overlap=overlap, dtype=dtype)
+                       overlap=overlap, dtype=dtype, voxel_encoder=vfe)
     return cfg, ecfg, sd, enc, bb
 
 
@@ -147,8 +156,17 @@ def cpu_baseline(cfg, ecfg, sd, points, workload):
     if workload == 'nusc':
         feats = O.vfe_mean(v, n, ecfg['in_channels'])
     else:
-        feats = np.random.default_rng(7).normal(0, 1, (c.shape[0], ecfg['in_channels'])) \
-            .astype(np.float32)
+        vcfg = cfg['pts_voxel_encoder']
+        layers = []
+        for i in range(len(vcfg['feat_channels'])):
+            p = f'vfe.vfe_layers.{i}'
+            layers.append((sd[f'{p}.linear.weight'],
+                           {k: sd[f'{p}.norm.{k}'] for k in ('weight', 'bias', 'running_mean',
+                                                              'running_var')}))
+        feats = O.hard_vfe(v, n, O.batch_coors([c]), layers, vcfg['voxel_size'],
+                           vcfg['point_cloud_range'], vcfg['norm_cfg']['eps'],
+                           vcfg['with_cluster_center'], vcfg['with_voxel_center'])
+    sd = {k: v for k, v in sd.items() if not k.startswith('vfe.')}
     wcfg = {k: ecfg[k] for k in ('base_channels', 'output_channels', 'encoder_channels',
                                  'encoder_paddings', 'block_type') if k in ecfg}
     bev = O.sparse_encoder_forward(sd, feats, O.batch_coors([c]), 1, ecfg['sparse_shape'],
@@ -203,15 +221,13 @@ def main():
     # frames in flight: independent frames on independent streams fill each other's tail rounds
     # and barrier bubbles; every stream has its own workspace, weights are shared
     lanes = [bb] + [LidarBackbone(cfg['pts_voxel_layer'], enc, dev, max_pts, batch_size=B,
-                                  overlap=not args.no_overlap, dtype=args.dtype)
+                                  overlap=not args.no_overlap, dtype=args.dtype,
+                                  voxel_encoder=bb.vfe)
                     for _ in range(args.streams - 1)]
     streams = [torch.cuda.Stream(device=dev) for _ in lanes]
     frames = [[torch.from_numpy(host_frames[f * B + b]).to(dev) for b in range(B)]
               for f in range(args.frames)]
     vf = None
-    if args.workload == 'waymo':  # learned 64-ch VFE is outside this path: seeded N(0,1) features
-        g = torch.Generator(device='cpu').manual_seed(7)
-        vf = torch.randn((bb.sets[0]['bound'], ecfg['in_channels']), generator=g).to(dev)
     torch.cuda.synchronize()
 
     with torch.no_grad():
@@ -310,7 +326,7 @@ def main():
                                     f'0.075 m voxels, sparse_shape 41x1440x1440), {prec}, {B} frame(s) '
                                     'per step' if args.workload == 'nusc' else
                                     'Waymo-shaped stress frame (transfusion_waymo_voxel_L: 0.1 m '
-                                    f'voxels, 41x1504x1504, 64-ch encoder input), {prec}'),
+                                    f'voxels, 41x1504x1504, HardVFE 5->64 + SparseEncoder), {prec}'),
                        'frames_per_step': B, 'distinct_frames_per_rank': args.frames,
                        'points_per_frame': int(np.mean([p.shape[0] for p in host_frames])),
                        'voxels_frame0': detail['counts'][0] if detail else None,
@@ -323,7 +339,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cb, bev_cpu = cpu_baseline(cfg, ecfg, sd, host_frames[0], args.workload)
             line['cpu_baseline'] = cb
-            if args.workload == 'nusc' and B == 1 and args.dtype == 'f32':  # same frame, same math
+            if B == 1 and args.dtype == 'f32':  # same frame, same math: the GPU result must match
                 with torch.no_grad():
                     got = bb.enqueue(frames[0], vf).cpu().numpy()
                 err = float(np.abs(got - bev_cpu).max() / max(np.abs(bev_cpu).max(), 1e-30))

@@ -89,6 +89,22 @@ SF_API int sf_voxel_mean(const float *voxels, const int *num_points_per_voxel, c
                          int m_bound, int max_points, int f, int num_features, float *out,
                          int out_stride, void *stream);
 
+/* Replaces one VFELayer of HardVFE (mmdet3d/models/voxel_encoders/voxel_encoder.py:383-450 for the
+ * decorations and the padding mask, mmdet3d/models/voxel_encoders/utils.py:61-96 for the layer):
+ * Linear(bias=False) -> BatchNorm1d (eval, folded into scale/shift) -> ReLU -> max over the
+ * max_points slots, in one kernel.
+ *  inputs (m, max_points, cin_raw) f32; weight (cout, cin) f32 = nn.Linear.weight with
+ *  cin = cin_raw + 3*[bit0] + 3*[bit1] + [bit2].
+ *  decorate bits (first layer only): 1 cluster-centre offsets, 2 voxel-centre offsets (needs
+ *  coors4 (b,z,y,x), voxel_size, coors_range), 4 distance to origin, 8 zero the slots >= num_points.
+ *  mode 0: out (m, cout) = max over slots (max_out, not cat_max); 1: out (m, max_points, cout)
+ *  point-wise (max_out False); 2: out (m, max_points, 2*cout) = [point-wise, repeated max]. */
+SF_API int sf_vfe_layer(const float *inputs, int cin_raw, int max_points, const int *num_points,
+                        const int *coors4, const int *m_dev, int m_bound, int decorate,
+                        const float voxel_size[3], const float coors_range[6], const float *weight,
+                        int cout, const float *scale, const float *shift, int mode, float *out,
+                        void *stream);
+
 /* Replaces SparseFusionDetector.extract_voxel_heights (mmdet3d/models/detectors/sparsefusion.py:73-112):
  * min_height / max_height (batch, ny, nx) f32 = per BEV cell (y / out_size_factor,
  * x / out_size_factor) minimum / maximum point z over the voxels in the cell, a z of exactly 0

@@ -125,6 +125,57 @@ def voxel_heights(voxels, coors4, batch, grid_xyz, out_size_factor):
     return mn, mx
 
 
+def vfe_layer(inputs, weight, bn, eps=1e-3, max_out=True, cat_max=True):
+    """VFELayer.forward (mmdet3d/models/voxel_encoders/utils.py:61-96) with eval-mode BatchNorm1d:
+    inputs (M, P, C), weight (Cout, C) = nn.Linear.weight, bn = dict(weight, bias, running_mean,
+    running_var)."""
+    x = _f32(inputs) @ _f32(weight).T                                      # :85  linear, no bias
+    x = (x - _f32(bn['running_mean'])) / np.sqrt(_f32(bn['running_var']) + np.float32(eps)) \
+        * _f32(bn['weight']) + _f32(bn['bias'])                            # :86  norm over channels
+    pointwise = np.maximum(x, 0).astype(np.float32)                        # :88
+    if not max_out:
+        return pointwise                                                   # :93-95
+    aggregated = pointwise.max(axis=1, keepdims=True)                      # :91  ALL P slots
+    if not cat_max:
+        return aggregated[:, 0]                                            # :97-98
+    return np.concatenate([pointwise, np.repeat(aggregated, inputs.shape[1], 1)], 2)   # :100-104
+
+
+def hard_vfe_decorate(features, num_points, coors, voxel_size, point_cloud_range,
+                      with_cluster_center=False, with_voxel_center=False):
+    """HardVFE.forward up to the VFE layers (mmdet3d/models/voxel_encoders/voxel_encoder.py:404-441):
+    decorations, then zero every slot >= num_points.  coors rows are (b, z, y, x)."""
+    f = _f32(features)
+    ls = [f]
+    if with_cluster_center:                                                # :407-413
+        mean = f[:, :, :3].sum(axis=1, keepdims=True) / \
+            np.asarray(num_points, np.float32).reshape(-1, 1, 1)
+        ls.append(f[:, :, :3] - mean)
+    if with_voxel_center:                                                  # :416-428
+        vx, vy, vz = (np.float32(v) for v in voxel_size)
+        off = [np.float32(voxel_size[i] / 2 + point_cloud_range[i]) for i in range(3)]
+        c = np.asarray(coors)
+        fc = np.zeros(f.shape[:2] + (3,), np.float32)
+        fc[:, :, 0] = f[:, :, 0] - (c[:, 3].astype(np.float32)[:, None] * vx + off[0])
+        fc[:, :, 1] = f[:, :, 1] - (c[:, 2].astype(np.float32)[:, None] * vy + off[1])
+        fc[:, :, 2] = f[:, :, 2] - (c[:, 1].astype(np.float32)[:, None] * vz + off[2])
+        ls.append(fc)
+    x = np.concatenate(ls, -1)                                             # :435
+    mask = np.asarray(num_points).reshape(-1, 1) > np.arange(f.shape[1]).reshape(1, -1)   # :439-441
+    return (x * mask[:, :, None]).astype(np.float32)
+
+
+def hard_vfe(features, num_points, coors, layers, voxel_size, point_cloud_range, eps=1e-3,
+             with_cluster_center=False, with_voxel_center=False):
+    """HardVFE.forward (:383-450) without a fusion layer.  layers = [(weight, bn), ...]; every
+    layer but the last concatenates (cat_max), the last returns the per-voxel max (:349-361)."""
+    x = hard_vfe_decorate(features, num_points, coors, voxel_size, point_cloud_range,
+                          with_cluster_center, with_voxel_center)
+    for i, (w, bn) in enumerate(layers):
+        x = vfe_layer(x, w, bn, eps, True, i != len(layers) - 1)
+    return x
+
+
 def batch_coors(coors_list):
     """detectors/sparsefusion.py:153-157: prepend the sample index."""
     out = []

@@ -29,6 +29,8 @@ SIGNATURES = {
     'sf_hard_voxelize': (_i, [_vp, _i, _i, _f3, _f6, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i,
                               _vp, _i, _vp, C.POINTER(_i), _vp, _sz, _vp]),
     'sf_voxel_mean': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    'sf_vfe_layer': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _f3, _f6, _vp, _i, _vp, _vp, _i, _vp,
+                          _vp]),
     'sf_voxel_heights': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'sf_hash_capacity': (_i, [_ll]),
     'sf_hash_build': (_i, [_vp, _vp, _i, _i3, _i, _vp, _vp, _i, _vp, _vp]),

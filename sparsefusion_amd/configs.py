@@ -36,6 +36,16 @@ WAYMO = dict(
         voxel_size=[0.1, 0.1, 0.15],
         max_voxels=150000,
         point_cloud_range=[-75.2, -75.2, -2, 75.2, 75.2, 4]),
+    pts_voxel_encoder=dict(
+        type='HardVFE',
+        in_channels=5,
+        feat_channels=[64],
+        with_distance=False,
+        with_cluster_center=False,
+        with_voxel_center=False,
+        voxel_size=[0.1, 0.1, 0.15],
+        norm_cfg=dict(type='BN1d', eps=0.001, momentum=0.01),
+        point_cloud_range=[-75.2, -75.2, -2, 75.2, 75.2, 4]),
     pts_middle_encoder=dict(
         type='SparseEncoder',
         in_channels=64,

@@ -56,7 +56,8 @@ def _flatten_encoder(enc):
 class LidarBackbone:
 
     def __init__(self, voxel_layer_cfg, encoder, device, max_points, batch_size=1,
-                 materialize_voxels=True, training=False, overlap=True, dtype='f32'):
+                 materialize_voxels=True, training=False, overlap=True, dtype='f32',
+                 voxel_encoder=None):
         """dtype 'f32': every layer on the exact-fp32 kernels.  'bf16' (BASELINE configs[2]): the
         first layer stays fp32 (raw metric coordinates need more than 8 significant bits), its
         output is cast to bf16, every later layer runs on the bf16 matrix cores with fp32
@@ -64,6 +65,14 @@ class LidarBackbone:
         assert isinstance(encoder, SparseEncoder)
         assert dtype in ('f32', 'bf16')
         self.dtype = dtype
+        # voxel_encoder: None = the fused HardSimpleVFE mean (nuScenes config); a HardVFE module
+        # (Waymo config, voxel_encoder.py:283-450) runs its VFE layers on the materialised voxels
+        self.vfe = voxel_encoder
+        if voxel_encoder is not None:
+            from .voxel_encoder import HardVFE
+            if not isinstance(voxel_encoder, HardVFE) or voxel_encoder._with_distance:
+                raise NotImplementedError('LidarBackbone takes a HardVFE (without with_distance)')
+            materialize_voxels = True
         L = self.L = _lib.lib()
         self.dev = torch.device(device)
         self.B = int(batch_size)
@@ -169,6 +178,17 @@ class LidarBackbone:
             self.fbufs.setdefault((d, lay.cout, lay.out_dtype),
                                   [torch.empty((self.sets[d]['bound'], lay.cout),
                                                dtype=lay.out_dtype, device=dev) for _ in range(3)])
+        self.vfe_bufs = []
+        if self.vfe is not None:
+            for lay in self.vfe.vfe_layers:
+                if lay.norm.training:
+                    raise RuntimeError('LidarBackbone needs eval-mode BatchNorm in the voxel encoder')
+                co = lay.linear.out_features
+                shape = (n0, self.mp, 2 * co) if lay.cat_max else (n0, co)
+                self.vfe_bufs.append(f32(*shape))
+            if self.vfe_bufs[-1].shape[1] != self.cin_pad:
+                raise RuntimeError('voxel encoder output channels must equal the (padded) encoder '
+                                   'input channels')
         self.cast0 = None
         if dtype == 'bf16' and len(self.layers) > 1:     # bf16 copy of the first layer's output
             l0 = self.layers[0]
@@ -189,6 +209,11 @@ class LidarBackbone:
             lay.scale, lay.shift = spconv.fold_bn(lay.bn)
             if lay.conv.bias is not None:
                 lay.shift = (lay.shift + lay.conv.bias.detach().float() * lay.scale).contiguous()
+        self.vfe_params = []
+        if self.vfe is not None:
+            for vl in self.vfe.vfe_layers:
+                sc, sh = spconv.fold_bn(vl.norm)
+                self.vfe_params.append((vl.linear.weight.detach().float().contiguous(), sc, sh))
 
     def memory_bytes(self):
         tot = 0
@@ -204,6 +229,7 @@ class LidarBackbone:
         for bufs in self.fbufs.values():
             yield from bufs
         yield from (self.rb_ws, self.vox_ws, self.mean, self.num_points, self.bev)
+        yield from self.vfe_bufs
         if self.cast0 is not None:
             yield self.cast0
         if self.voxels is not None:
@@ -232,7 +258,7 @@ class LidarBackbone:
         ovf = c0 + 4 * len(self.sets)
         self.counts.zero_()
         s0 = self.sets[0]
-        if voxel_features is None and self.in_channels > self.F:
+        if voxel_features is None and self.vfe is None and self.in_channels > self.F:
             raise RuntimeError(f'encoder wants {self.in_channels} input channels but points have '
                                f'{self.F} features: pass voxel_features')
         nf = min(self.in_channels, self.F)
@@ -245,7 +271,8 @@ class LidarBackbone:
                 _lib.ptr(pts), pts.shape[0], self.F, _lib.f3(self.voxel_size),
                 _lib.f6(self.pc_range), self.mp, self.mv,
                 self.voxels.data_ptr() if self.materialize else None, s0['indices'].data_ptr(), 4,
-                b, self.num_points.data_ptr(), self.mean.data_ptr(), nf, self.cin_pad, c0,
+                b, self.num_points.data_ptr(),
+                self.mean.data_ptr() if self.vfe is None else None, nf, self.cin_pad, c0,
                 s0['bound'], ovf, None, self.vox_ws.data_ptr(), self.vox_ws_bytes, st))
         # ---- coordinate phase: on its own stream, forked after the voxelizer ---------------
         # The hash / neighbour-table kernels are latency bound and need no LDS: they run in the
@@ -293,6 +320,19 @@ class LidarBackbone:
         waited = set()
         # ---- feature phase -----------------------------------------------------------------
         x, x_ch = self.mean, self.cin_pad
+        if self.vfe is not None and voxel_features is None:
+            v = self.vfe
+            deco = (1 if v._with_cluster_center else 0) | (2 if v._with_voxel_center else 0) | 8
+            cur, cur_c = self.voxels, self.F
+            for i, (lay, (w, sc, sh)) in enumerate(zip(v.vfe_layers, self.vfe_params)):
+                chk(L.sf_vfe_layer(
+                    cur.data_ptr(), cur_c, self.mp, self.num_points.data_ptr(),
+                    s0['indices'].data_ptr(), c0, s0['bound'], deco if i == 0 else 0,
+                    _lib.f3(v.voxel_size), _lib.f6(list(v.point_cloud_range)), w.data_ptr(),
+                    lay.linear.out_features, sc.data_ptr(), sh.data_ptr(),
+                    2 if lay.cat_max else 0, self.vfe_bufs[i].data_ptr(), st))
+                cur, cur_c = self.vfe_bufs[i], 2 * lay.linear.out_features
+            x = self.vfe_bufs[-1]
         if voxel_features is not None:
             _lib.require(voxel_features, torch.float32, 'voxel_features')
             if voxel_features.shape[0] < s0['bound'] or voxel_features.shape[1] != self.cin_pad:

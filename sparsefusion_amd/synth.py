@@ -189,3 +189,22 @@ def encoder_state_dict(seed, in_channels, layout='spconv2', **cfg):
         sd[f'{bn}.running_var'] = rng.uniform(0.5, 1.5, co).astype(np.float32)
         sd[f'{bn}.num_batches_tracked'] = np.asarray(0, np.int64)
     return sd
+
+
+def hard_vfe_state_dict(seed, in_channels, feat_channels):
+    """Random-init state dict (numpy) for HardVFE(in_channels (decorated), feat_channels) under
+    the reference's key names (vfe_layers.N.linear.weight, vfe_layers.N.norm.*)."""
+    rng = np.random.default_rng(seed)
+    sd = {}
+    chans = [in_channels] + list(feat_channels)
+    for i in range(len(chans) - 1):
+        cin = chans[i] * (2 if i > 0 else 1)
+        co = chans[i + 1]
+        sd[f'vfe_layers.{i}.linear.weight'] = (rng.uniform(-1, 1, (co, cin)) *
+                                               math.sqrt(3.0 / cin)).astype(np.float32)
+        sd[f'vfe_layers.{i}.norm.weight'] = rng.uniform(0.5, 1.5, co).astype(np.float32)
+        sd[f'vfe_layers.{i}.norm.bias'] = rng.normal(0, 0.1, co).astype(np.float32)
+        sd[f'vfe_layers.{i}.norm.running_mean'] = rng.normal(0, 0.1, co).astype(np.float32)
+        sd[f'vfe_layers.{i}.norm.running_var'] = rng.uniform(0.5, 1.5, co).astype(np.float32)
+        sd[f'vfe_layers.{i}.norm.num_batches_tracked'] = np.asarray(0, np.int64)
+    return sd

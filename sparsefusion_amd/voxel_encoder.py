@@ -27,3 +27,109 @@ class HardSimpleVFE(nn.Module):
             f, self.num_features, out.data_ptr(), self.num_features,
             _lib.stream(features.device)))
         return out
+
+
+class VFELayer(nn.Module):
+    """mmdet3d/models/voxel_encoders/utils.py:31-96: Linear(bias=False) -> BN1d -> ReLU -> max over
+    the points of a voxel [-> concat].  Same attributes / state-dict keys (`linear`, `norm`)."""
+
+    def __init__(self, in_channels, out_channels, norm_cfg=dict(type='BN1d', eps=1e-3, momentum=0.01),
+                 max_out=True, cat_max=True):
+        super().__init__()
+        from .registry import build_norm_layer
+        self.fp16_enabled = False
+        self.cat_max = cat_max
+        self.max_out = max_out
+        self.norm = build_norm_layer(norm_cfg, out_channels)[1]
+        self.linear = nn.Linear(in_channels, out_channels, bias=False)
+
+    def _run(self, inputs, decorate=0, num_points=None, coors=None, voxel_size=None, pc_range=None):
+        from . import spconv
+        _lib.require(inputs, torch.float32, 'inputs')
+        if self.norm.training:
+            raise NotImplementedError('VFELayer runs eval-mode BatchNorm only (the LiDAR branch '
+                                      'is frozen in the target configs)')
+        m, p, c = inputs.shape
+        cout = self.linear.out_features
+        scale, shift = spconv.fold_bn(self.norm)
+        mode = 1 if not self.max_out else (2 if self.cat_max else 0)
+        shape = {0: (m, cout), 1: (m, p, cout), 2: (m, p, 2 * cout)}[mode]
+        out = torch.empty(shape, dtype=torch.float32, device=inputs.device)
+        _lib.check(_lib.lib().sf_vfe_layer(
+            _lib.ptr(inputs.contiguous()), c, p,
+            _lib.ptr(num_points.int().contiguous()) if num_points is not None else None,
+            _lib.ptr(coors.int().contiguous()) if coors is not None else None, None, m, decorate,
+            _lib.f3(voxel_size) if voxel_size is not None else None,
+            _lib.f6(pc_range) if pc_range is not None else None,
+            _lib.ptr(self.linear.weight.detach().float().contiguous()), cout, _lib.ptr(scale),
+            _lib.ptr(shift), mode, out.data_ptr(), _lib.stream(inputs.device)))
+        return out
+
+    def forward(self, inputs):
+        return self._run(inputs)
+
+
+@VOXEL_ENCODERS.register_module()
+class HardVFE(nn.Module):
+    """Drop-in for mmdet3d/models/voxel_encoders/voxel_encoder.py:283-450 (the voxel encoder of
+    configs/transfusion_waymo_voxel_L.py:114-124).  The decorations, the padding mask and the
+    first VFELayer run as ONE kernel; image fusion (`fusion_layer`) belongs to the camera branch
+    and is not built."""
+
+    def __init__(self, in_channels=4, feat_channels=[], with_distance=False,
+                 with_cluster_center=False, with_voxel_center=False, voxel_size=(0.2, 0.2, 4),
+                 point_cloud_range=(0, -40, -3, 70.4, 40, 1),
+                 norm_cfg=dict(type='BN1d', eps=1e-3, momentum=0.01), mode='max', fusion_layer=None,
+                 return_point_feats=False):
+        super().__init__()
+        assert len(feat_channels) > 0
+        if fusion_layer is not None:
+            raise NotImplementedError('point/image fusion layers are outside the LiDAR hot path')
+        if with_cluster_center:
+            in_channels += 3
+        if with_voxel_center:
+            in_channels += 3
+        if with_distance:
+            in_channels += 3      # sic: the reference reserves 3 channels for ONE distance column
+        self.in_channels = in_channels
+        self._with_distance = with_distance
+        self._with_cluster_center = with_cluster_center
+        self._with_voxel_center = with_voxel_center
+        self.return_point_feats = return_point_feats
+        self.fp16_enabled = False
+        self.vx, self.vy, self.vz = voxel_size[0], voxel_size[1], voxel_size[2]
+        self.x_offset = self.vx / 2 + point_cloud_range[0]
+        self.y_offset = self.vy / 2 + point_cloud_range[1]
+        self.z_offset = self.vz / 2 + point_cloud_range[2]
+        self.voxel_size = list(voxel_size)
+        self.point_cloud_range = point_cloud_range
+        from .scatter_points import DynamicScatter
+        self.scatter = DynamicScatter(voxel_size, point_cloud_range, True)
+        chans = [self.in_channels] + list(feat_channels)
+        layers = []
+        for i in range(len(chans) - 1):
+            cin, cout = chans[i], chans[i + 1]
+            if i > 0:
+                cin *= 2
+            last = i == len(chans) - 2
+            layers.append(VFELayer(cin, cout, norm_cfg=norm_cfg, max_out=True, cat_max=not last))
+        self.vfe_layers = nn.ModuleList(layers)
+        self.num_vfe = len(layers)
+        self.fusion_layer = None
+
+    def forward(self, features, num_points, coors, img_feats=None, img_metas=None):
+        """features (M, P, C) f32, num_points (M,), coors (M, 4) (b, z, y, x) -> (M, feat_channels[-1])."""
+        if self._with_distance:
+            # the reference's own forward fails here: it builds Linear(C+3, ...) but concatenates
+            # one distance column (voxel_encoder.py:337-338 vs :430-432)
+            raise NotImplementedError('with_distance: the reference allots 3 channels to a '
+                                      '1-channel decoration and cannot run this configuration')
+        deco = (1 if self._with_cluster_center else 0) | (2 if self._with_voxel_center else 0) | 8
+        x = features
+        for i, vfe in enumerate(self.vfe_layers):
+            if i == 0:
+                x = vfe._run(x, deco, num_points, coors, self.voxel_size,
+                             list(self.point_cloud_range))
+            else:
+                x = vfe(x)
+        return x

@@ -80,3 +80,44 @@ def test_voxel_cap_inside_pipeline(dev, oracle):
     res = bb.results()
     assert np.array_equal(res['coors'].cpu().numpy(), coors4)
     assert_close(bev.cpu().numpy(), expect, 1e-4)
+
+
+def test_backbone_with_hard_vfe_waymo_style(dev, oracle):
+    """Waymo-config shape of the path (configs/transfusion_waymo_voxel_L.py:109-134): voxelize
+    (max 5 points) -> HardVFE 5->64 -> SparseEncoder(in_channels=64), all inside the pipeline."""
+    from sparsefusion_amd import synth
+    from sparsefusion_amd.voxel_encoder import HardVFE
+    from helpers import torch_state_dict
+    enc, sd, cfg = make_encoder(dev, 64, 31, name='waymo')
+    vfe = HardVFE(in_channels=5, feat_channels=[64], voxel_size=SMALL_VOXEL,
+                  point_cloud_range=SMALL_RANGE, norm_cfg=dict(type='BN1d', eps=1e-3, momentum=0.01))
+    vsd = synth.hard_vfe_state_dict(32, 5, [64])
+    vfe.load_state_dict(torch_state_dict(vsd))
+    vfe = vfe.to(dev).eval()
+    vl = dict(VL, max_num_points=5, max_voxels=6000)
+    frames = [small_points(700 + b, 3000 + 800 * b) for b in range(2)]
+    bb = LidarBackbone(vl, enc, dev, max_points=8000, batch_size=2, voxel_encoder=vfe)
+    with torch.no_grad():
+        bev = bb([to_dev(p, dev) for p in frames]).clone()
+    res = bb.results()
+    assert res['overflow'] == 0
+    vox, coors, nums = [], [], []
+    for p in frames:
+        v, c, n = oracle.hard_voxelize(p, SMALL_VOXEL, SMALL_RANGE, 5, 6000)
+        vox.append(v), coors.append(c), nums.append(n)
+    coors4 = oracle.batch_coors(coors)
+    layers = [(vsd['vfe_layers.0.linear.weight'],
+               {k: vsd[f'vfe_layers.0.norm.{k}'] for k in ('weight', 'bias', 'running_mean',
+                                                           'running_var')})]
+    feats = oracle.hard_vfe(np.concatenate(vox), np.concatenate(nums), coors4, layers, SMALL_VOXEL,
+                            SMALL_RANGE, 1e-3)
+    expect = oracle.sparse_encoder_forward(sd, feats, coors4, 2, SMALL_SHAPE, 64, **weight_cfg(cfg),
+                                           encoder_paddings=cfg['encoder_paddings'])
+    assert np.array_equal(res['coors'].cpu().numpy(), coors4)
+    assert_close(bb.vfe_bufs[-1][:coors4.shape[0]].cpu().numpy(), feats, 1e-5, 1e-6)
+    assert_close(bev.cpu().numpy(), expect, 1e-4)
+    # module path: Voxelization -> HardVFE -> SparseEncoder gives the same tensor
+    with torch.no_grad():
+        f = vfe(res['voxels'], res['num_points'], res['coors'])
+        bev2 = enc(f, res['coors'], 2)
+    assert torch.equal(bev, bev2)
