@@ -124,18 +124,20 @@ def time_layers(bb, pts, vf, iters=5):
     return acc / iters  # ms per layer
 
 
-def measured_traffic(cin, cout):
+def measured_traffic(cin, cout, bf16=False):
     """HBM-side bytes per launch of the conv instantiation, from the committed PMC passes
     (profiles/r01_pmc_hbm_traffic.json: tools/pmc_traffic.sh, FETCH_SIZE doubled as the gfx950
     note in MI355X_MICROARCH.md prescribes, WRITE_SIZE as read).  Counters cannot be collected
     inside this process; None when the file has no such kernel."""
     import re
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')
+    path = os.path.join(ROOT, 'profiles',
+                        'r01_pmc_hbm_traffic_bf16.json' if bf16 else 'r01_pmc_hbm_traffic.json')
     if not os.path.exists(path):
         return None
     with open(path) as f:
         table = json.load(f)
-    pat = re.compile(r'sparse_conv_f32(_wide)?_kernel<%d, %d,' % (cin, cout))
+    pat = re.compile((r'conv_bf16_(tile|direct)_kernel<%d, %d,' if bf16 else
+                      r'sparse_conv_f32(_wide|_direct)?_kernel<%d, %d,') % (cin, cout))
     hits = [v for k, v in table.items() if pat.match(k)]
     if not hits:
         return None
@@ -298,6 +300,7 @@ def main():
                                 frac=round(ach / PEAK_HBM_GBS, 4), traffic=None)
             if dom[2]:
                 roofline['kernel'] = f'conv_bf16_kernel<{max(dom[0], 16)},{dom[1]}>'
+                roofline['traffic'] = measured_traffic(max(dom[0], 16), dom[1], True)
             else:
                 roofline['kernel'] = f'sparse_conv_f32_kernel<{dom[0] if dom[0] > 8 else 8},{dom[1]}>'
                 roofline['traffic'] = measured_traffic(dom[0] if dom[0] > 8 else 8, dom[1])
