@@ -262,6 +262,35 @@ SF_API int sf_dense_bev(const float *features, const int *indices, const int *n_
 SF_API int sf_pad_channels_f32(const float *src, int c_src, float *dst, int c_dst,
                                const int *n_dev, int n_bound, void *stream);
 
+/* ------------------------------------------------------------------ BEV backbone / neck */
+
+/* Bytes of the packed filter image of one dense 2-D layer (0 for a bad shape).  `up` > 1 is a
+ * transposed convolution with kernel = stride = up (ksize must then be 1, see below). */
+SF_API size_t sf_conv2d_packed_bytes(int cout, int cin, int ksize, int up);
+
+/* Re-orders the filters of one nn.Conv2d (mmdet3d/models/backbones/second.py:38-55,
+ * necks/second_fpn.py:54-59; weight (cout, cin, ksize, ksize) f32) into the MFMA fragment order
+ * sf_conv2d_f32 streams.  A transposed convolution with kernel = stride = up
+ * (second_fpn.py:46-51, nn.ConvTranspose2d weight (cin, cout, up, up)) is handed over as the
+ * equivalent up*up 1x1 filters: weight (up*up*cout, cin) with row (dy*up + dx)*cout + co =
+ * w[:, co, dy, dx], ksize = 1.  packed holds sf_conv2d_packed_bytes(cout, cin, ksize, up) bytes. */
+SF_API int sf_conv2d_pack_filters_f32(const float *weight, int cout, int cin, int ksize, int up,
+                                      float *packed, void *stream);
+
+/* One Conv2d / ConvTranspose2d(k = s) + BatchNorm2d(eval) + ReLU of SECOND / SECONDFPN
+ * (second.py:36-60,82-86; second_fpn.py:61-63,86-91) as a single launch, fp32 on the matrix
+ * cores (exact fp32 FMA chains), NCHW:
+ *   in  (batch, cin, h, w);   out (batch, out_channels, up*ho, up*wo), of which channels
+ *   [out_channel_offset, out_channel_offset + cout) are written (the rest untouched: a neck's
+ *   deblocks write straight into the concatenated map), ho = (h + 2*pad - ksize)/stride + 1;
+ *   out = relu?(conv(in) * scale[co] + shift[co]); scale / shift (cout) or NULL (1 / 0).
+ * Supported (ksize, stride): (3,1), (3,2), (1,1), (2,2); dilation 1, groups 1, no bias (fold a
+ * bias into shift).  up > 1 needs ksize = 1, stride = 1, pad = 0. */
+SF_API int sf_conv2d_f32(const float *in, const float *packed, const float *scale,
+                         const float *shift, float *out, int batch, int cin, int h, int w, int cout,
+                         int ksize, int stride, int pad, int up, int out_channels,
+                         int out_channel_offset, int relu, void *stream);
+
 /* ------------------------------------------------------------------ dynamic scatter -- */
 
 /* Per-dimension maximum of coors (n, ndim) i32 into max_dev[ndim] (device; -1 where n == 0 or all

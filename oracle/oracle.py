@@ -433,3 +433,58 @@ def sparse_encoder_forward(state_dict, voxel_features, coors, batch_size, sparse
         trace['out_indices'] = idx
         trace['out_shape'] = list(shape)
     return bev
+
+
+# ------------------------------------------------------------------ BEV backbone / neck
+# The reference's SECOND / SECONDFPN are chains of torch modules (nn.Conv2d, nn.ConvTranspose2d,
+# nn.BatchNorm2d(eps=1e-3), nn.ReLU), so the reference's CPU arithmetic IS torch's CPU kernels: the
+# oracle calls the same functional ops in fp32 on the host.  tests/test_oracle_second.py pins this
+# transcription against a direct numpy statement of the two convolutions on small shapes.
+
+def _bn2d(sd, prefix):
+    return {k: np.asarray(sd[f'{prefix}.{k}'], np.float32)
+            for k in ('weight', 'bias', 'running_mean', 'running_var')}
+
+
+def conv2d_bn_relu(x, weight, bn, stride, padding, eps=1e-3, bias=None, transposed=False):
+    """relu(BatchNorm2d_eval(conv(x))): one conv -> norm -> ReLU triple of
+    mmdet3d/models/backbones/second.py:37-57 / necks/second_fpn.py:61-63."""
+    import torch
+    import torch.nn.functional as F
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a, np.float32))
+    with torch.no_grad():
+        if transposed:
+            y = F.conv_transpose2d(t(x), t(weight), t(bias), stride=stride)
+        else:
+            y = F.conv2d(t(x), t(weight), t(bias), stride=stride, padding=padding)
+        y = F.batch_norm(y, t(bn['running_mean']), t(bn['running_var']), t(bn['weight']),
+                         t(bn['bias']), False, 0.0, eps)
+        return F.relu(y).numpy()
+
+
+def second_forward(sd, x, layer_nums=(3, 5, 5), layer_strides=(2, 2, 2), eps=1e-3):
+    """SECOND.forward (second.py:73-86) with the block layout of second.py:36-60: state-dict keys
+    blocks.I.{0,3,6,...}.weight (conv) and blocks.I.{1,4,7,...}.* (BatchNorm2d)."""
+    outs = []
+    for i, (n, s) in enumerate(zip(layer_nums, layer_strides)):
+        for j in range(n + 1):
+            x = conv2d_bn_relu(x, sd[f'blocks.{i}.{3 * j}.weight'], _bn2d(sd, f'blocks.{i}.{3 * j + 1}'),
+                               s if j == 0 else 1, 1, eps, sd.get(f'blocks.{i}.{3 * j}.bias'))
+        outs.append(x)
+    return tuple(outs)
+
+
+def second_fpn_forward(sd, xs, upsample_strides=(1, 2, 4), use_conv_for_no_stride=False, eps=1e-3):
+    """SECONDFPN.forward (second_fpn.py:76-92): deblock i = deconv(k = s = stride) when stride > 1 or
+    (stride == 1 and not use_conv_for_no_stride), else conv(k = s = round(1/stride))
+    (second_fpn.py:43-59); outputs concatenated along channels."""
+    ups = []
+    for i, (x, stride) in enumerate(zip(xs, upsample_strides)):
+        w, bn = sd[f'deblocks.{i}.0.weight'], _bn2d(sd, f'deblocks.{i}.1')
+        b = sd.get(f'deblocks.{i}.0.bias')
+        if stride > 1 or (stride == 1 and not use_conv_for_no_stride):
+            ups.append(conv2d_bn_relu(x, w, bn, stride, 0, eps, b, transposed=True))
+        else:
+            s = int(np.round(1 / stride))
+            ups.append(conv2d_bn_relu(x, w, bn, s, 0, eps, b))
+    return [np.concatenate(ups, axis=1) if len(ups) > 1 else ups[0]]

@@ -55,6 +55,10 @@ SIGNATURES = {
     'sf_sparse_conv_bf16': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp,
                                  _i, _vp, _i, _vp]),
     'sf_dense_bev': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    'sf_conv2d_packed_bytes': (_sz, [_i, _i, _i, _i]),
+    'sf_conv2d_pack_filters_f32': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    'sf_conv2d_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
+                           _vp]),
     'sf_pad_channels_f32': (_i, [_vp, _i, _vp, _i, _vp, _i, _vp]),
     'sf_coors_max': (_i, [_vp, _i, _i, _vp, _vp]),
     'sf_dynamic_scatter_workspace': (_sz, [C.POINTER(C.c_int), _i]),

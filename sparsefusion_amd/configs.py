@@ -1,9 +1,9 @@
 """Hot-path hyper-parameters of the two reference configs this build targets.
 
-nuScenes: configs/sparsefusion_nusc_voxel_LC_r50.py:1,6,153-170.
-Waymo:    configs/transfusion_waymo_voxel_L.py:1-3,109-134.
+nuScenes: configs/sparsefusion_nusc_voxel_LC_r50.py:1,6,153-186.
+Waymo:    configs/transfusion_waymo_voxel_L.py:1-3,109-150.
 The dict keys are the reference's own (`pts_voxel_layer`, `pts_voxel_encoder`,
-`pts_middle_encoder`), so a reference config can be passed through unchanged.
+`pts_middle_encoder`, `pts_backbone`, `pts_neck`), so a reference config can be passed through unchanged.
 """
 
 NUSC = dict(
@@ -25,6 +25,22 @@ NUSC = dict(
         encoder_channels=((16, 16, 32), (32, 32, 64), (64, 64, 128), (128, 128)),
         encoder_paddings=((0, 0, 1), (0, 0, 1), (0, 0, [0, 1, 1]), (0, 0)),
         block_type='basicblock'),
+    pts_backbone=dict(
+        type='SECOND',
+        in_channels=256,
+        out_channels=[128, 256],
+        layer_nums=[5, 5],
+        layer_strides=[1, 2],
+        norm_cfg=dict(type='BN', eps=0.001, momentum=0.01),
+        conv_cfg=dict(type='Conv2d', bias=False)),
+    pts_neck=dict(
+        type='SECONDFPN',
+        in_channels=[128, 256],
+        out_channels=[256, 256],
+        upsample_strides=[1, 2],
+        norm_cfg=dict(type='BN', eps=0.001, momentum=0.01),
+        upsample_cfg=dict(type='deconv', bias=False),
+        use_conv_for_no_stride=True),
 )
 
 WAYMO = dict(
@@ -55,4 +71,20 @@ WAYMO = dict(
         encoder_channels=((16, 16, 32), (32, 32, 64), (64, 64, 128), (128, 128)),
         encoder_paddings=((0, 0, 1), (0, 0, 1), (0, 0, [0, 1, 1]), (0, 0)),
         block_type='basicblock'),
+    pts_backbone=dict(
+        type='SECOND',
+        in_channels=256,
+        out_channels=[128, 256],
+        layer_nums=[5, 5],
+        layer_strides=[1, 2],
+        norm_cfg=dict(type='BN', eps=0.001, momentum=0.01),
+        conv_cfg=dict(type='Conv2d', bias=False)),
+    pts_neck=dict(
+        type='SECONDFPN',
+        in_channels=[128, 256],
+        out_channels=[256, 256],
+        upsample_strides=[1, 2],
+        norm_cfg=dict(type='BN', eps=0.001, momentum=0.01),
+        upsample_cfg=dict(type='deconv', bias=False),
+        use_conv_for_no_stride=True),
 )

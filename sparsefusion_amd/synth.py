@@ -208,3 +208,44 @@ def hard_vfe_state_dict(seed, in_channels, feat_channels):
         sd[f'vfe_layers.{i}.norm.running_var'] = rng.uniform(0.5, 1.5, co).astype(np.float32)
         sd[f'vfe_layers.{i}.norm.num_batches_tracked'] = np.asarray(0, np.int64)
     return sd
+
+
+def _bn2d_state(rng, sd, prefix, co):
+    sd[f'{prefix}.weight'] = rng.uniform(0.5, 1.5, co).astype(np.float32)
+    sd[f'{prefix}.bias'] = rng.normal(0, 0.1, co).astype(np.float32)
+    sd[f'{prefix}.running_mean'] = rng.normal(0, 0.1, co).astype(np.float32)
+    sd[f'{prefix}.running_var'] = rng.uniform(0.5, 1.5, co).astype(np.float32)
+    sd[f'{prefix}.num_batches_tracked'] = np.asarray(0, np.int64)
+
+
+def second_state_dict(seed, in_channels, out_channels, layer_nums, **_):
+    """Random-init state dict (numpy) for SECOND under the reference's key names
+    (blocks.I.{0,3,..}.weight, blocks.I.{1,4,..}.*): He-uniform filters, BN statistics as in
+    encoder_state_dict."""
+    rng = np.random.default_rng(seed)
+    sd = {}
+    cins = [in_channels, *out_channels[:-1]]
+    for i, n in enumerate(layer_nums):
+        for j in range(n + 1):
+            ci, co = (cins[i] if j == 0 else out_channels[i]), out_channels[i]
+            bound = math.sqrt(6.0 / (9 * ci))
+            sd[f'blocks.{i}.{3 * j}.weight'] = rng.uniform(-bound, bound, (co, ci, 3, 3)).astype(np.float32)
+            _bn2d_state(rng, sd, f'blocks.{i}.{3 * j + 1}', co)
+    return sd
+
+
+def second_fpn_state_dict(seed, in_channels, out_channels, upsample_strides,
+                          use_conv_for_no_stride=False, **_):
+    """Random-init state dict (numpy) for SECONDFPN (deblocks.I.0.weight, deblocks.I.1.*)."""
+    rng = np.random.default_rng(seed)
+    sd = {}
+    for i, (ci, co, s) in enumerate(zip(in_channels, out_channels, upsample_strides)):
+        if s > 1 or (s == 1 and not use_conv_for_no_stride):
+            shape = (ci, co, s, s)                      # nn.ConvTranspose2d
+        else:
+            k = int(np.round(1 / s))
+            shape = (co, ci, k, k)                      # nn.Conv2d
+        bound = math.sqrt(6.0 / ci)
+        sd[f'deblocks.{i}.0.weight'] = rng.uniform(-bound, bound, shape).astype(np.float32)
+        _bn2d_state(rng, sd, f'deblocks.{i}.1', co)
+    return sd
