@@ -22,10 +22,10 @@ def _bn(rng, c):
                 running_var=rng.uniform(0.5, 1.5, c).astype(np.float32))
 
 
-def _layer(dev, x, w, bn, k, s, p, up=1, relu=True, out_channels=None, off=0):
+def _layer(dev, x, w, bn, k, s, p, up=1, relu=True, out_channels=None, off=0, transposed=False):
     """One raw C-ABI call (no module)."""
     L = _lib.lib()
-    if up > 1:
+    if transposed:
         cin, cout = w.shape[:2]
         mat = np.ascontiguousarray(np.transpose(w, (2, 3, 1, 0)).reshape(up * up * cout, cin))
     else:
@@ -33,18 +33,19 @@ def _layer(dev, x, w, bn, k, s, p, up=1, relu=True, out_channels=None, off=0):
         mat = w
     packed = torch.empty(L.sf_conv2d_packed_bytes(cout, cin, k, up) // 4, device=dev)
     st = _lib.stream(dev)
-    _lib.check(L.sf_conv2d_pack_filters_f32(to_dev(mat, dev).data_ptr(), cout, cin, k, up,
-                                            packed.data_ptr(), st))
     scale = bn['weight'] / np.sqrt(bn['running_var'] + 1e-3)
     shift = bn['bias'] - bn['running_mean'] * scale
+    # device operands stay referenced until the kernel has run (a temporary's block would be reused)
+    d_mat, d_x = to_dev(mat, dev), to_dev(x, dev)
+    d_scale, d_shift = to_dev(scale.astype(np.float32), dev), to_dev(shift.astype(np.float32), dev)
+    _lib.check(L.sf_conv2d_pack_filters_f32(d_mat.data_ptr(), cout, cin, k, up, packed.data_ptr(), st))
     B, _, H, W = x.shape
     ho, wo = ((H + 2 * p - k) // s + 1) * up, ((W + 2 * p - k) // s + 1) * up
     ctot = out_channels or cout
     out = torch.full((B, ctot, ho, wo), -7.0, device=dev)
-    _lib.check(L.sf_conv2d_f32(to_dev(x, dev).data_ptr(), packed.data_ptr(),
-                               to_dev(scale.astype(np.float32), dev).data_ptr(),
-                               to_dev(shift.astype(np.float32), dev).data_ptr(), out.data_ptr(), B,
-                               cin, H, W, cout, k, s, p, up, ctot, off, int(relu), st))
+    _lib.check(L.sf_conv2d_f32(d_x.data_ptr(), packed.data_ptr(), d_scale.data_ptr(),
+                               d_shift.data_ptr(), out.data_ptr(), B, cin, H, W, cout, k, s, p, up,
+                               ctot, off, int(relu), st))
     torch.cuda.synchronize()
     return out.cpu().numpy()
 
@@ -75,7 +76,7 @@ def test_deconv_layer_into_channel_slice(dev, oracle, up, cin, cout, B, H, W):
     x = rng.normal(0, 1, (B, cin, H, W)).astype(np.float32)
     w = (rng.uniform(-1, 1, (cin, cout, up, up)) * np.sqrt(3.0 / cin)).astype(np.float32)
     bn = _bn(rng, cout)
-    got = _layer(dev, x, w, bn, 1, 1, 0, up=up, out_channels=cout + 11, off=7)
+    got = _layer(dev, x, w, bn, 1, 1, 0, up=up, out_channels=cout + 11, off=7, transposed=True)
     assert_close(got[:, 7:7 + cout], oracle.conv2d_bn_relu(x, w, bn, up, 0, 1e-3, transposed=True))
     assert np.all(got[:, :7] == -7.0) and np.all(got[:, 7 + cout:] == -7.0)   # untouched channels
 
