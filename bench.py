@@ -40,7 +40,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA dense peak (no 2:1 sparsity)
 
 
-def build_backbone(workload, dev, batch, max_points, overlap=True, dtype='f32'):
+def build_backbone(workload, dev, batch, max_points, overlap=True, dtype='f32', second=False):
     cfg = configs.NUSC if workload == 'nusc' else configs.WAYMO
     ecfg = dict(cfg['pts_middle_encoder'])
     ecfg.pop('type')
@@ -59,8 +59,20 @@ def build_backbone(workload, dev, batch, max_points, overlap=True, dtype='f32'):
         vfe.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in vsd.items()})
         vfe = vfe.to(dev).eval()
         sd = dict(sd, **{'vfe.' + k: v for k, v in vsd.items()})
+    bev_backbone = neck = None
+    if second:   # the BEV backbone and neck the map feeds (not part of the headline)
+        from sparsefusion_amd.second import SECOND, SECONDFPN
+        bcfg, ncfg = dict(cfg['pts_backbone']), dict(cfg['pts_neck'])
+        bcfg.pop('type'), ncfg.pop('type')
+        bev_backbone, neck = SECOND(**bcfg), SECONDFPN(**ncfg)
+        bev_backbone.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in
+                                      synth.second_state_dict(2026, **bcfg).items()})
+        neck.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in
+                              synth.second_fpn_state_dict(2027, **ncfg).items()})
+        bev_backbone, neck = bev_backbone.to(dev).eval(), neck.to(dev).eval()
     bb = LidarBackbone(cfg['pts_voxel_layer'], enc, dev, max_points, batch_size=batch,
-                       overlap=overlap, dtype=dtype, voxel_encoder=vfe)
+                       overlap=overlap, dtype=dtype, voxel_encoder=vfe, bev_backbone=bev_backbone,
+                       neck=neck)
     return cfg, ecfg, sd, enc, bb
 
 
@@ -194,6 +206,9 @@ def main():
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
                     help="f32 = the headline config (BASELINE configs[1]); bf16 = configs[2] "
                          "(bf16 MFMA, fp32 accumulation; use with --batch 8)")
+    ap.add_argument('--second', action='store_true',
+                    help='also run SECOND + SECONDFPN on the BEV map inside the step (SURVEY 8f-3; '
+                         'an extended workload, not the headline metric)')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-overlap', action='store_true',
                     help='coordinate phase on the main stream instead of a forked one')
@@ -219,12 +234,12 @@ def main():
     host_frames = [gen(i) for i in ids]
     max_pts = max(p.shape[0] for p in host_frames)
     cfg, ecfg, sd, enc, bb = build_backbone(args.workload, dev, B, max_pts, not args.no_overlap,
-                                            args.dtype)
+                                            args.dtype, args.second)
     # frames in flight: independent frames on independent streams fill each other's tail rounds
     # and barrier bubbles; every stream has its own workspace, weights are shared
     lanes = [bb] + [LidarBackbone(cfg['pts_voxel_layer'], enc, dev, max_pts, batch_size=B,
                                   overlap=not args.no_overlap, dtype=args.dtype,
-                                  voxel_encoder=bb.vfe)
+                                  voxel_encoder=bb.vfe, bev_backbone=bb.bev_backbone, neck=bb.neck)
                     for _ in range(args.streams - 1)]
     streams = [torch.cuda.Stream(device=dev) for _ in lanes]
     frames = [[torch.from_numpy(host_frames[f * B + b]).to(dev) for b in range(B)]
@@ -333,6 +348,7 @@ def main():
                        'frames_per_step': B, 'distinct_frames_per_rank': args.frames,
                        'points_per_frame': int(np.mean([p.shape[0] for p in host_frames])),
                        'voxels_frame0': detail['counts'][0] if detail else None,
+                       'bev_backbone': 'SECOND + SECONDFPN (fp32) on the BEV map' if args.second else None,
                        'hip_graph': not args.no_graph, 'frames_in_flight': args.streams, 'sharding': 'frames by rank, no collective'},
             'roofline': roofline,
         }
@@ -344,7 +360,8 @@ def main():
             line['cpu_baseline'] = cb
             if B == 1 and args.dtype == 'f32':  # same frame, same math: the GPU result must match
                 with torch.no_grad():
-                    got = bb.enqueue(frames[0], vf).cpu().numpy()
+                    bb.enqueue(frames[0], vf)
+                    got = bb.bev.cpu().numpy()
                 err = float(np.abs(got - bev_cpu).max() / max(np.abs(bev_cpu).max(), 1e-30))
                 line['parity_vs_cpu_rel_err'] = err
         else:

@@ -272,8 +272,9 @@ SF_API size_t sf_conv2d_packed_bytes(int cout, int cin, int ksize, int up);
  * necks/second_fpn.py:54-59; weight (cout, cin, ksize, ksize) f32) into the MFMA fragment order
  * sf_conv2d_f32 streams.  A transposed convolution with kernel = stride = up
  * (second_fpn.py:46-51, nn.ConvTranspose2d weight (cin, cout, up, up)) is handed over as the
- * equivalent up*up 1x1 filters: weight (up*up*cout, cin) with row (dy*up + dx)*cout + co =
- * w[:, co, dy, dx], ksize = 1.  packed holds sf_conv2d_packed_bytes(cout, cin, ksize, up) bytes. */
+ * equivalent up*up 1x1 filters: weight (up*up*cout, cin) with row (dy*cout + co)*up + dx =
+ * w[:, co, dy, dx] (dx fastest: a lane's 4 consecutive packed channels are consecutive output
+ * x, stored as one 8 / 16-byte piece), ksize = 1.  packed holds sf_conv2d_packed_bytes(cout, cin, ksize, up) bytes. */
 SF_API int sf_conv2d_pack_filters_f32(const float *weight, int cout, int cin, int ksize, int up,
                                       float *packed, void *stream);
 

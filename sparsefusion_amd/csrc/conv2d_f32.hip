@@ -9,7 +9,9 @@
 //   * the product is taken transposed, out^T = W^T * patch: the filters are MFMA operand A, the
 //     pixels operand B, so a lane ends with 4 output channels of ONE pixel column and 16 lanes
 //     cover 16 consecutive x of a channel plane -> 64-byte NCHW stores with no LDS transpose;
-//   * input channels go through LDS 8 at a time, double buffered, one barrier per stage: the
+//   * input channels go through LDS 8 at a time (32 for 1x1), double buffered, one barrier per
+//     stage, every global load of the next stage issued branch-free before the current stage's
+//     MFMAs (addresses clamped, values masked; the fill plan of a thread is computed once): the
 //     input patch (TH*S+KS-S rows x 32*S+KS-S columns, zero padded at the borders, read from HBM/L2
 //     once per stage and reused by all KS*KS taps and all 64 output channels), and the stage's
 //     filters, which the host packed in fragment order so that the fill is a straight 16-byte copy
@@ -21,8 +23,8 @@
 //     cycles) on 8 independent accumulators;
 //   * transposed convolutions with kernel = stride (`up`) are `up*up` independent 1x1 convolutions
 //     whose results interleave in the output: they run as ONE 1x1 launch over up*up*Cout packed
-//     output channels, the epilogue sends channel (tap, co) of pixel (y, x) to
-//     (co, up*y + tap/up, up*x + tap%up);
+//     output channels ordered (dy, co, dx); the epilogue sends channel (dy, co, dx) of pixel
+//     (y, x) to (co, up*y + dy, up*x + dx), dx pairs / quads of a lane as one 8 / 16-byte store;
 //   * the epilogue applies y = acc*scale[co] + shift[co] (eval BatchNorm folded by the caller),
 //     ReLU, and writes into channels [out_coff, out_coff + Cout) of a buffer with out_ctot
 //     channels, so SECONDFPN's torch.cat (second_fpn.py:88-89) costs nothing.
@@ -35,8 +37,8 @@ namespace {
 
 constexpr int TW = 32;  // output columns per workgroup row
 constexpr int TN = 64;  // output channels per workgroup
-constexpr int CK = 8;   // input channels per LDS stage
-constexpr int CKG = CK / 4;
+// input channels per LDS stage: 8 for 3x3 / 2x2 (72 / 32 MFMAs per wave and barrier), 32 for 1x1
+constexpr int stage_channels(int ks) { return ks == 1 ? 32 : 8; }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -50,6 +52,8 @@ struct Conv2dArgs {
 
 template <int KS, int S, int TH>
 struct Geo {
+  static constexpr int CK = stage_channels(KS);
+  static constexpr int CKG = CK / 4;
   static constexpr int TAPS = KS * KS;
   static constexpr int PH = (TH - 1) * S + KS;
   static constexpr int PW = (TW - 1) * S + KS;
@@ -57,11 +61,13 @@ struct Geo {
   static constexpr int W4 = TAPS * CKG * 64;  // float4 per filter stage
   static constexpr int W_FLOATS = W4 * 4;
   static constexpr int P_ELEMS = CK * PH * PW;
-  static constexpr int STAGE = W_FLOATS + CK * CS;
+  static constexpr int DUMMY = CK * CS;          // patch slot that absorbs out-of-range fill lanes
+  static constexpr int STAGE = W_FLOATS + CK * CS + 4;
   static constexpr int THREADS = TH * 64;
   static constexpr int NW4 = (W4 + THREADS - 1) / THREADS;
   static constexpr int NP = (P_ELEMS + THREADS - 1) / THREADS;
   static constexpr size_t LDS_BYTES = 2u * STAGE * sizeof(float);
+  static_assert(NP <= 32, "okmask holds one bit per patch element of a thread");
 };
 
 template <int KS, int S, int TH>
@@ -90,24 +96,42 @@ conv2d_f32_kernel(const float *__restrict__ in, const f32x4 *__restrict__ wp,
   const float *__restrict__ inb = in + (size_t)b * a.Cin * plane;
   const f32x4 *__restrict__ wct = wp + (size_t)ct * a.nchunks * G::W4;
 
+  // Fill plan of this thread, fixed for the whole layer: element e of the patch image ->
+  // offset inside the channel-chunk of the input (or -1 outside the map) and LDS slot.
+  int goff[G::NP], loff[G::NP];
+#pragma unroll
+  for (int i = 0; i < G::NP; ++i) {
+    const int e = tid + i * G::THREADS;
+    const int c = e / (G::PH * G::PW), rem = e - c * (G::PH * G::PW);
+    const int r = rem / G::PW, j = rem - r * G::PW;
+    const int iy = iy0 + r, ix = ix0 + j;
+    const bool in_map = e < G::P_ELEMS && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    goff[i] = in_map ? c * (int)plane + iy * a.W + ix : -1;
+    loff[i] = e < G::P_ELEMS ? c * G::CS + rem : G::DUMMY;
+  }
+
   f32x4 wreg[G::NW4];
   float preg[G::NP];
+  unsigned okmask = 0;  // bit i: preg[i] is a real input element (else the slot is zero padding)
 
+  // All loads are unconditional (clamped address; the value is masked only when it is written to
+  // LDS, after the current stage's MFMAs): no branch and no early wait, so every load of the next
+  // stage stays in flight under the matrix work.
   auto load_stage = [&](int ch) {
 #pragma unroll
     for (int i = 0; i < G::NW4; ++i) {
-      const int idx = tid + i * G::THREADS;
-      if (G::W4 % G::THREADS == 0 || idx < G::W4) wreg[i] = wct[(size_t)ch * G::W4 + idx];
+      int idx = tid + i * G::THREADS;
+      if (G::W4 % G::THREADS != 0) idx = idx < G::W4 ? idx : G::W4 - 1;
+      wreg[i] = wct[(size_t)ch * G::W4 + idx];
     }
-    const int c0 = ch * CK;
+    const int c0 = ch * G::CK, cbase = c0 * (int)plane;
+    okmask = 0;
 #pragma unroll
     for (int i = 0; i < G::NP; ++i) {
       const int e = tid + i * G::THREADS;
-      const int c = e / (G::PH * G::PW), rem = e - c * (G::PH * G::PW);
-      const int r = rem / G::PW, j = rem - r * G::PW;
-      const int iy = iy0 + r, ix = ix0 + j;
-      const bool ok = e < G::P_ELEMS && c0 + c < a.Cin && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-      preg[i] = ok ? inb[(size_t)(c0 + c) * plane + (size_t)iy * a.W + ix] : 0.0f;
+      const bool ok = goff[i] >= 0 && (a.Cin % G::CK == 0 || c0 + e / (G::PH * G::PW) < a.Cin);
+      preg[i] = inb[ok ? cbase + goff[i] : 0];
+      okmask |= (unsigned)ok << i;
     }
   };
   auto store_stage = [&](int buf) {
@@ -118,11 +142,8 @@ conv2d_f32_kernel(const float *__restrict__ in, const f32x4 *__restrict__ wp,
       if (G::W4 % G::THREADS == 0 || idx < G::W4) reinterpret_cast<f32x4 *>(st)[idx] = wreg[i];
     }
 #pragma unroll
-    for (int i = 0; i < G::NP; ++i) {
-      const int e = tid + i * G::THREADS;
-      const int c = e / (G::PH * G::PW), rem = e - c * (G::PH * G::PW);
-      if (e < G::P_ELEMS) st[G::W_FLOATS + c * G::CS + rem] = preg[i];
-    }
+    for (int i = 0; i < G::NP; ++i)
+      st[G::W_FLOATS + loff[i]] = (okmask >> i) & 1u ? preg[i] : 0.0f;
   };
 
   f32x4 acc[4][2];
@@ -149,8 +170,8 @@ conv2d_f32_kernel(const float *__restrict__ in, const f32x4 *__restrict__ wp,
 #pragma unroll
         for (int kx = 0; kx < KS; ++kx)
 #pragma unroll
-          for (int cg = 0; cg < CKG; ++cg) {
-            const f32x4 wa = wl[((ky * KS + kx) * CKG + cg) * 64];
+          for (int cg = 0; cg < G::CKG; ++cg) {
+            const f32x4 wa = wl[((ky * KS + kx) * G::CKG + cg) * 64];
             const float b0 = pl[cg * 4 * G::CS + ky * G::PW + kx];
             const float b1 = pl[cg * 4 * G::CS + ky * G::PW + kx + 16 * S];
 #pragma unroll
@@ -164,47 +185,108 @@ conv2d_f32_kernel(const float *__restrict__ in, const f32x4 *__restrict__ wp,
     __syncthreads();
   }
 
-  // epilogue: lane holds channels n0 + g*16 + 4*(lane>>4) + i of pixel columns ox0 + p*16 + (lane&15)
+  // epilogue: lane holds packed channels cp0 + i (cp0 = n0 + g*16 + 4*(lane>>4), i = 0..3) of pixel
+  // columns ox0 + p*16 + (lane&15).  Packed channel order is (dy, co, dx): for up = 2 / 4 the
+  // lane's consecutive channels are consecutive x of one output row -> 8 / 16-byte stores.
   if (!row_live) return;
   const int oy = oy0 + wr;
   const int up = a.up, HO = a.Ho * up, WO = a.Wo * up;
 #pragma unroll
-  for (int g = 0; g < 4; ++g)
+  for (int g = 0; g < 4; ++g) {
+    const int cp0 = ct * TN + g * 16 + 4 * (lane >> 4);
+    if (up == 1) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int cp = ct * TN + g * 16 + 4 * (lane >> 4) + i;
-      if (cp >= a.cout_packed) continue;
-      const int tap = cp / a.cout, co = cp - tap * a.cout;
+      for (int i = 0; i < 4; ++i) {
+        const int co = cp0 + i;
+        if (co >= a.cout) continue;
+        const float sc = scale ? scale[co] : 1.0f, sh = shift ? shift[co] : 0.0f;
+        float *__restrict__ orow = out + (((size_t)b * a.out_ctot + a.out_coff + co) * HO + oy) * WO;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const int ox = ox0 + p * 16 + (lane & 15);
+          if (ox < a.Wo) {
+            float v = acc[g][p][i] * sc + sh;
+            if (a.relu) v = fmaxf(v, 0.0f);
+            orow[ox] = v;
+          }
+        }
+      }
+    } else if (up == 2) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int cq = (cp0 >> 1) + h;  // (dy, co)
+        if (cq >= 2 * a.cout) continue;
+        const int dy = cq / a.cout, co = cq - dy * a.cout;
+        const float sc = scale ? scale[co] : 1.0f, sh = shift ? shift[co] : 0.0f;
+        float *__restrict__ orow =
+            out + (((size_t)b * a.out_ctot + a.out_coff + co) * HO + (size_t)oy * 2 + dy) * WO;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const int ox = ox0 + p * 16 + (lane & 15);
+          if (ox < a.Wo) {
+            float2 v = make_float2(acc[g][p][2 * h] * sc + sh, acc[g][p][2 * h + 1] * sc + sh);
+            if (a.relu) v.x = fmaxf(v.x, 0.0f), v.y = fmaxf(v.y, 0.0f);
+            *reinterpret_cast<float2 *>(orow + (size_t)ox * 2) = v;
+          }
+        }
+      }
+    } else if (up == 4) {
+      const int cq = cp0 >> 2;  // (dy, co)
+      if (cq >= 4 * a.cout) continue;
+      const int dy = cq / a.cout, co = cq - dy * a.cout;
       const float sc = scale ? scale[co] : 1.0f, sh = shift ? shift[co] : 0.0f;
-      const int dy = tap / up, dx = tap - dy * up;
       float *__restrict__ orow =
-          out + (((size_t)b * a.out_ctot + a.out_coff + co) * HO + (size_t)oy * up + dy) * WO + dx;
+          out + (((size_t)b * a.out_ctot + a.out_coff + co) * HO + (size_t)oy * 4 + dy) * WO;
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
         const int ox = ox0 + p * 16 + (lane & 15);
         if (ox < a.Wo) {
-          float v = acc[g][p][i] * sc + sh;
-          if (a.relu) v = fmaxf(v, 0.0f);
-          orow[(size_t)ox * up] = v;
+          float4 v = make_float4(acc[g][p][0] * sc + sh, acc[g][p][1] * sc + sh,
+                                 acc[g][p][2] * sc + sh, acc[g][p][3] * sc + sh);
+          if (a.relu)
+            v.x = fmaxf(v.x, 0.0f), v.y = fmaxf(v.y, 0.0f), v.z = fmaxf(v.z, 0.0f),
+            v.w = fmaxf(v.w, 0.0f);
+          *reinterpret_cast<float4 *>(orow + (size_t)ox * 4) = v;
+        }
+      }
+    } else {  // any other upsampling factor: scalar stores
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int cp = cp0 + i;
+        if (cp >= a.cout_packed) continue;
+        const int dx = cp % up, cq = cp / up, dy = cq / a.cout, co = cq - dy * a.cout;
+        const float sc = scale ? scale[co] : 1.0f, sh = shift ? shift[co] : 0.0f;
+        float *__restrict__ orow =
+            out + (((size_t)b * a.out_ctot + a.out_coff + co) * HO + (size_t)oy * up + dy) * WO + dx;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const int ox = ox0 + p * 16 + (lane & 15);
+          if (ox < a.Wo) {
+            float v = acc[g][p][i] * sc + sh;
+            if (a.relu) v = fmaxf(v, 0.0f);
+            orow[(size_t)ox * up] = v;
+          }
         }
       }
     }
+  }
 }
 
-// (Cout', Cin, KS, KS) -> [cout tile][stage][tap][4-channel group][lane][4 channel groups of 16]
+// (Cout', Cin, KS, KS) -> [cout tile][stage][tap][4-channel group][lane][4 channel groups of 16];
+// for an upsampling layer the caller's rows are already in packed order (dy, co, dx)
 __global__ void conv2d_pack_kernel(const float *__restrict__ w, int coutp, int cin, int taps,
-                                   int nct, int nchunks, f32x4 *__restrict__ wp) {
-  const long long total = (long long)nct * nchunks * taps * CKG * 64;
+                                   int nct, int nchunks, int ckg, f32x4 *__restrict__ wp) {
+  const long long total = (long long)nct * nchunks * taps * ckg * 64;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const int lane = (int)(i & 63);
     long long r = i >> 6;
-    const int cg = (int)(r % CKG);
-    r /= CKG;
+    const int cg = (int)(r % ckg);
+    r /= ckg;
     const int tap = (int)(r % taps);
     r /= taps;
     const int ch = (int)(r % nchunks), ct = (int)(r / nchunks);
-    const int ci = ch * CK + cg * 4 + (lane >> 4);
+    const int ci = (ch * ckg + cg) * 4 + (lane >> 4);
     f32x4 v;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -246,33 +328,30 @@ int dispatch_th(int th, const float *in, const float *wp, const float *scale, co
   }
 }
 
-// Rows per workgroup: the candidate whose busiest CU finishes first (workgroups are dealt evenly
-// over 256 CUs; a workgroup's time is proportional to its rows), larger tiles on ties because the
-// filters are re-read once per workgroup.
-int pick_rows(const Conv2dArgs &a, int stride) {
+// Rows (= waves) per workgroup.  4 puts one wave of every workgroup on each SIMD and measured
+// best whenever the grid is several workgroups per CU (B = 8: 107 TFLOP/s against 82-86 with 3 or
+// 6 rows, whose waves load the four SIMDs unevenly; 2 rows: 66).  6 rows are taken only where
+// they save a whole round of workgroups on the 256 CUs (a 90x90 map at batch 1: 180 workgroups
+// instead of 276).
+int pick_rows(const Conv2dArgs &a) {
   if (const char *e = getenv("SF_CONV2D_TH")) {
     const int v = atoi(e);
     if (v == 2 || v == 3 || v == 4 || v == 6) return v;
   }
-  static const int cand[4] = {6, 4, 3, 2};
-  int best = 2;
-  long long best_cost = -1;
-  for (int i = 0; i < 4; ++i) {
-    const int th = cand[i];
-    if (stride == 2 && th == 6) continue;  // patch image would not leave room for 2 workgroups per CU
+  auto cost = [&](int th) {
     const long long wgs = (long long)a.B * sf_div_up(a.Ho, th) * a.nxt * a.nct;
-    const long long cost = ((wgs + 255) / 256) * th;
-    if (best_cost < 0 || cost < best_cost) best_cost = cost, best = th;
-  }
-  return best;
+    return ((wgs + 255) / 256) * th;
+  };
+  return 10 * cost(6) <= 8 * cost(4) ? 6 : 4;
 }
 
 }  // namespace
 
 extern "C" size_t sf_conv2d_packed_bytes(int cout, int cin, int ksize, int up) {
   if (cout < 1 || cin < 1 || ksize < 1 || up < 1) return 0;
-  const size_t nct = (size_t)sf_div_up((long long)cout * up * up, TN), nch = sf_div_up(cin, CK);
-  return nct * nch * ksize * ksize * CKG * 64 * sizeof(f32x4);
+  const int ck = stage_channels(ksize);
+  const size_t nct = (size_t)sf_div_up((long long)cout * up * up, TN), nch = sf_div_up(cin, ck);
+  return nct * nch * ksize * ksize * (ck / 4) * 64 * sizeof(f32x4);
 }
 
 extern "C" int sf_conv2d_pack_filters_f32(const float *weight, int cout, int cin, int ksize, int up,
@@ -281,10 +360,11 @@ extern "C" int sf_conv2d_pack_filters_f32(const float *weight, int cout, int cin
   SF_CHECK_ARG(cout >= 1 && cin >= 1 && up >= 1, "bad filter shape");
   SF_CHECK_ARG(ksize >= 1 && ksize <= 3, "kernel size %d not supported (1, 2, 3)", ksize);
   SF_CHECK_ARG(up == 1 || ksize == 1, "an upsampling layer is packed as up*up 1x1 filters");
-  const int coutp = cout * up * up, nct = sf_div_up(coutp, TN), nch = sf_div_up(cin, CK);
-  const long long total = (long long)nct * nch * ksize * ksize * CKG * 64;
+  const int ck = stage_channels(ksize);
+  const int coutp = cout * up * up, nct = sf_div_up(coutp, TN), nch = sf_div_up(cin, ck);
+  const long long total = (long long)nct * nch * ksize * ksize * (ck / 4) * 64;
   hipLaunchKernelGGL(conv2d_pack_kernel, dim3(sf_grid(total, 256)), dim3(256), 0,
-                     (hipStream_t)stream, weight, coutp, cin, ksize * ksize, nct, nch,
+                     (hipStream_t)stream, weight, coutp, cin, ksize * ksize, nct, nch, ck / 4,
                      reinterpret_cast<f32x4 *>(packed));
   SF_CHECK_LAUNCH();
   return SF_OK;
@@ -309,10 +389,11 @@ extern "C" int sf_conv2d_f32(const float *in, const float *packed, const float *
   a.cout_packed = cout * up * up, a.cout = cout, a.up = up;
   a.out_ctot = out_channels, a.out_coff = out_channel_offset, a.relu = relu;
   a.nct = sf_div_up(a.cout_packed, TN), a.nxt = sf_div_up(wo, TW), a.nyt = 0;
-  a.nchunks = sf_div_up(cin, CK), a.n_wg = 0;
+  a.nchunks = sf_div_up(cin, stage_channels(ksize)), a.n_wg = 0;
+  SF_CHECK_ARG((long long)cin * h * w < (1ll << 31), "one sample of the input must stay below 2^31 elements");
   SF_CHECK_ARG((long long)batch * sf_div_up(ho, 2) * a.nxt * a.nct < (1ll << 30), "grid too large");
   hipStream_t st = (hipStream_t)stream;
-  const int th = pick_rows(a, stride);
+  const int th = pick_rows(a);
   if (ksize == 3 && stride == 1) return dispatch_th<3, 1>(th, in, packed, scale, shift, out, a, st);
   if (ksize == 3 && stride == 2) return dispatch_th<3, 2>(th, in, packed, scale, shift, out, a, st);
   if (ksize == 1 && stride == 1) return dispatch_th<1, 1>(th, in, packed, scale, shift, out, a, st);

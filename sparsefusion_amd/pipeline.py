@@ -57,7 +57,7 @@ class LidarBackbone:
 
     def __init__(self, voxel_layer_cfg, encoder, device, max_points, batch_size=1,
                  materialize_voxels=True, training=False, overlap=True, dtype='f32',
-                 voxel_encoder=None):
+                 voxel_encoder=None, bev_backbone=None, neck=None):
         """dtype 'f32': every layer on the exact-fp32 kernels.  'bf16' (BASELINE configs[2]): the
         first layer stays fp32 (raw metric coordinates need more than 8 significant bits), its
         output is cast to bf16, every later layer runs on the bf16 matrix cores with fp32
@@ -65,6 +65,13 @@ class LidarBackbone:
         assert isinstance(encoder, SparseEncoder)
         assert dtype in ('f32', 'bf16')
         self.dtype = dtype
+        # bev_backbone / neck: optional SECOND / SECONDFPN modules (second.py) run on the dense map
+        # in the same enqueue (detectors/sparsefusion.py:123-126); enqueue then returns what they
+        # return (the neck's single map, or the backbone's tuple) instead of the BEV map
+        self.bev_backbone, self.neck = bev_backbone, neck
+        if neck is not None and bev_backbone is None:
+            raise ValueError('a neck needs a bev_backbone')
+        self.bev_out = None
         # voxel_encoder: None = the fused HardSimpleVFE mean (nuScenes config); a HardVFE module
         # (Waymo config, voxel_encoder.py:283-450) runs its VFE layers on the materialised voxels
         self.vfe = voxel_encoder
@@ -386,7 +393,11 @@ class LidarBackbone:
         D, H, W = o['shape']
         chk(L.sf_dense_bev(x.data_ptr(), o['indices'].data_ptr(), c0 + 4 * self.out_set, o['bound'],
                            self.out_channels, self.B, D, H, W, self.bev.data_ptr(), st))
-        return self.bev
+        if self.bev_backbone is None:
+            return self.bev
+        feats = self.bev_backbone(self.bev)
+        self.bev_out = self.neck(feats)[0] if self.neck is not None else feats
+        return self.bev_out
 
     def __call__(self, points_list, voxel_features=None):
         return self.enqueue(points_list, voxel_features)

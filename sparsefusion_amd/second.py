@@ -66,6 +66,17 @@ class _PackedFilters:
 
     def __init__(self):
         self.key, self.packed = None, None
+        self.fold_key, self.fold_val = None, None
+
+    def fold(self, conv, bn):
+        """Folded eval-BatchNorm (scale, shift), recomputed only when a parameter or buffer changed
+        (a handful of tiny torch kernels per layer otherwise end up in every captured graph)."""
+        ts = [t for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var, conv.bias)
+              if t is not None]
+        key = tuple((t.data_ptr(), t._version) for t in ts) + (bn.eps,)
+        if key != self.fold_key:
+            self.fold_key, self.fold_val = key, _fold_bn2d(bn, conv.bias)
+        return self.fold_val
 
     def get(self, conv):
         w = conv.weight
@@ -76,7 +87,7 @@ class _PackedFilters:
         if isinstance(conv, nn.ConvTranspose2d):
             cin, cout, kh, kw = w.shape
             up, ks = kh, 1
-            mat = w.detach().permute(2, 3, 1, 0).reshape(kh * kw * cout, cin).contiguous()
+            mat = w.detach().permute(2, 1, 3, 0).reshape(kh * kw * cout, cin).contiguous()   # (dy, co, dx)
         else:
             cout, cin, kh, kw = w.shape
             up, ks = 1, kh
@@ -130,7 +141,7 @@ def conv_bn_relu(x, conv, bn, relu, cache, out=None, channel_offset=0):
         raise RuntimeError(f'layer output {(B, cout, ho, wo)} does not fit buffer {tuple(out.shape)}')
     fold = bn is None or (not bn.training and bn.running_mean is not None)
     if fold and bn is not None:
-        scale, shift = _fold_bn2d(bn, conv.bias)
+        scale, shift = cache.fold(conv, bn)
     elif conv.bias is not None:
         scale, shift = None, conv.bias.detach().float().contiguous()
     else:

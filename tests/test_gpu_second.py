@@ -27,7 +27,7 @@ def _layer(dev, x, w, bn, k, s, p, up=1, relu=True, out_channels=None, off=0, tr
     L = _lib.lib()
     if transposed:
         cin, cout = w.shape[:2]
-        mat = np.ascontiguousarray(np.transpose(w, (2, 3, 1, 0)).reshape(up * up * cout, cin))
+        mat = np.ascontiguousarray(np.transpose(w, (2, 1, 3, 0)).reshape(up * up * cout, cin))
     else:
         cout, cin = w.shape[:2]
         mat = w
@@ -162,3 +162,37 @@ def test_training_mode_bn_and_bias(dev):
     want = ref_block.cpu()(x.cpu())          # torch CPU modules = the reference's arithmetic
     second.to(dev)
     assert_close(got.detach().cpu().numpy(), want.detach().numpy(), rtol=1e-3, atol_scale=1e-4)
+
+
+def test_lidar_backbone_with_second_and_neck_in_one_graph(dev, oracle):
+    """voxelize -> mean -> SparseEncoder -> SECOND -> SECONDFPN as ONE captured enqueue
+    (detectors/sparsefusion.py:114-126) == the modules applied to the BEV map one by one (bit for
+    bit: same kernels) and == the oracle chain within the fp32 bar."""
+    from helpers import SMALL_RANGE, SMALL_VOXEL, small_points
+    from sparsefusion_amd.pipeline import LidarBackbone
+    from test_gpu_conv import make_encoder
+    from test_gpu_pipeline import oracle_bev
+    vl = dict(max_num_points=10, voxel_size=SMALL_VOXEL, max_voxels=(3000, 6000),
+              point_cloud_range=SMALL_RANGE)
+    enc, sd, cfg = make_encoder(dev, 5, 13)
+    bcfg = dict(in_channels=256, out_channels=[64, 128], layer_nums=[2, 2], layer_strides=[1, 2])
+    ncfg = dict(in_channels=[64, 128], out_channels=[64, 64], upsample_strides=[1, 2],
+                use_conv_for_no_stride=True)
+    _, _, bsd, nsd, second, neck = _modules(dev, bcfg, ncfg, 41)
+    frames = [small_points(500 + b, 4000 + 500 * b) for b in range(2)]
+    pts = [to_dev(p, dev) for p in frames]
+    bb = LidarBackbone(vl, enc, dev, max_points=8000, batch_size=2, bev_backbone=second, neck=neck)
+    with torch.no_grad():
+        g = bb.capture(pts)
+        g.replay()
+        torch.cuda.synchronize()
+        got, bev = bb.bev_out.clone(), bb.bev.clone()
+        want = neck(second(bev))[0]
+    assert torch.equal(got, want)
+    bev_o, _, _ = oracle_bev(oracle, sd, cfg, frames, 10, 6000)
+    assert_close(bev.cpu().numpy(), bev_o)
+    exp = oracle.second_fpn_forward(nsd, oracle.second_forward(bsd, bev_o, bcfg['layer_nums'],
+                                                               bcfg['layer_strides']),
+                                    ncfg['upsample_strides'], True)[0]
+    assert tuple(got.shape) == exp.shape
+    assert_close(got.cpu().numpy(), exp, rtol=2e-4, atol_scale=2e-5)   # two fp32 stages chained
