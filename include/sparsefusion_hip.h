@@ -94,9 +94,13 @@ SF_API int sf_voxel_mean(const float *voxels, const int *num_points_per_voxel, c
  * Linear(bias=False) -> BatchNorm1d (eval, folded into scale/shift) -> ReLU -> max over the
  * max_points slots, in one kernel.
  *  inputs (m, max_points, cin_raw) f32; weight (cout, cin) f32 = nn.Linear.weight with
- *  cin = cin_raw + 3*[bit0] + 3*[bit1] + [bit2].
+ *  cin = cin_raw + 3*[bit0] + (3 or 2)*[bit1] + [bit2].
  *  decorate bits (first layer only): 1 cluster-centre offsets, 2 voxel-centre offsets (needs
- *  coors4 (b,z,y,x), voxel_size, coors_range), 4 distance to origin, 8 zero the slots >= num_points.
+ *  coors4 (b,z,y,x), voxel_size, coors_range), 4 distance to origin, 8 zero the slots >= num_points,
+ *  16 the voxel-centre offset has x and y only, 32 it also overwrites raw x, y before the distance
+ *  is taken -- 16 / 32 make the layer the first PFNLayer of PillarFeatureNet
+ *  (mmdet3d/models/voxel_encoders/pillar_encoder.py:91-150 with legacy = bit 32; PFNLayer:
+ *  voxel_encoders/utils.py:106-180, last_layer -> mode 0, else mode 2).
  *  mode 0: out (m, cout) = max over slots (max_out, not cat_max); 1: out (m, max_points, cout)
  *  point-wise (max_out False); 2: out (m, max_points, 2*cout) = [point-wise, repeated max]. */
 SF_API int sf_vfe_layer(const float *inputs, int cin_raw, int max_points, const int *num_points,

@@ -176,6 +176,61 @@ def hard_vfe(features, num_points, coors, layers, voxel_size, point_cloud_range,
     return x
 
 
+def pillar_decorate(features, num_points, coors, voxel_size, point_cloud_range,
+                    with_cluster_center=True, with_voxel_center=True, with_distance=False,
+                    legacy=True):
+    """PillarFeatureNet.forward up to the PFN layers (mmdet3d/models/voxel_encoders/
+    pillar_encoder.py:103-145).  In legacy mode the reference's f_center is a VIEW of
+    features[:, :, :2] that is modified in place (:124-130), so the raw x / y columns carry the
+    offsets as well -- after f_cluster was computed (:105-110), before the distance is (:133-135)."""
+    f = _f32(features).copy()
+    ls = [f]
+    if with_cluster_center:                                                # :105-110
+        mean = f[:, :, :3].sum(axis=1, keepdims=True) / \
+            np.asarray(num_points, np.float32).reshape(-1, 1, 1)
+        ls.append(f[:, :, :3] - mean)
+    if with_voxel_center:                                                  # :114-131
+        vx, vy = np.float32(voxel_size[0]), np.float32(voxel_size[1])
+        xo = np.float32(voxel_size[0] / 2 + point_cloud_range[0])          # :86-87
+        yo = np.float32(voxel_size[1] / 2 + point_cloud_range[1])
+        c = np.asarray(coors)
+        fc = np.zeros(f.shape[:2] + (2,), np.float32)
+        fc[:, :, 0] = f[:, :, 0] - (c[:, 3].astype(np.float32)[:, None] * vx + xo)
+        fc[:, :, 1] = f[:, :, 1] - (c[:, 2].astype(np.float32)[:, None] * vy + yo)
+        if legacy:
+            f[:, :, :2] = fc                                               # the aliasing of :124
+        ls.append(fc)
+    if with_distance:                                                      # :133-135
+        ls.append(np.sqrt((f[:, :, :3] ** 2).sum(-1, keepdims=True)).astype(np.float32))
+    x = np.concatenate(ls, -1)                                             # :138
+    mask = np.asarray(num_points).reshape(-1, 1) > np.arange(f.shape[1]).reshape(1, -1)   # :142-145
+    return (x * mask[:, :, None]).astype(np.float32)
+
+
+def pillar_feature_net(features, num_points, coors, layers, voxel_size, point_cloud_range, eps=1e-3,
+                       with_cluster_center=True, with_voxel_center=True, with_distance=False,
+                       legacy=True):
+    """PillarFeatureNet.forward (:91-150), mode 'max'.  layers = [(weight, bn), ...]; a PFNLayer
+    (voxel_encoders/utils.py:159-180) is Linear -> BN -> ReLU -> max, concatenated with the
+    point-wise features unless it is the last one -- the arithmetic of vfe_layer."""
+    x = pillar_decorate(features, num_points, coors, voxel_size, point_cloud_range,
+                        with_cluster_center, with_voxel_center, with_distance, legacy)
+    for i, (w, bn) in enumerate(layers):
+        x = vfe_layer(x, w, bn, eps, True, i != len(layers) - 1)
+    return x
+
+
+def pillar_scatter(voxel_features, coors4, batch_size, ny, nx):
+    """PointPillarsScatter.forward_batch (mmdet3d/models/middle_encoders/pillar_scatter.py:62-101):
+    canvas[b][:, y * nx + x] = features, coors rows (b, z, y, x)."""
+    c = np.asarray(coors4)
+    out = np.zeros((batch_size, voxel_features.shape[1], ny * nx), np.float32)
+    for b in range(batch_size):
+        m = c[:, 0] == b
+        out[b][:, c[m, 2] * nx + c[m, 3]] = _f32(voxel_features)[m].T
+    return out.reshape(batch_size, voxel_features.shape[1], ny, nx)
+
+
 def batch_coors(coors_list):
     """detectors/sparsefusion.py:153-157: prepend the sample index."""
     out = []

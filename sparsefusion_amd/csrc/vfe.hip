@@ -1,4 +1,8 @@
-// Voxel feature encoder layer (HardVFE / VFELayer) for gfx950.
+// Voxel feature encoder layer (HardVFE / VFELayer, PillarFeatureNet / PFNLayer) for gfx950.
+//
+// PillarFeatureNet.forward (mmdet3d/models/voxel_encoders/pillar_encoder.py:91-150) + PFNLayer
+// (voxel_encoders/utils.py:106-180) are the same computation with a 2-channel voxel-centre offset
+// and, in legacy mode, raw x / y overwritten by it: decorate bits 16 and 32.
 //
 // Reference: HardVFE.forward (mmdet3d/models/voxel_encoders/voxel_encoder.py:383-450) decorates
 // the (M, P, C) voxel tensor (cluster-centre offsets :407-413, voxel-centre offsets :416-428,
@@ -21,6 +25,8 @@ __device__ __forceinline__ int load_n(const int *n_dev, int n_bound) {
 
 struct VfeDeco {
   int cluster, center, dist, mask;
+  int center_xy;  // PillarFeatureNet: the voxel-centre offset has x and y only (pillar_encoder.py:114-131)
+  int legacy;     // PillarFeatureNet(legacy=True): the offsets also overwrite raw x, y (:124-130)
   float vs[3];   // voxel size x, y, z
   float off[3];  // vs/2 + range_min per axis (voxel_encoder.py:363-365)
 };
@@ -77,12 +83,22 @@ vfe_layer_kernel(const float *__restrict__ in, int cin_raw, int P, const int *__
           xr[f++] = py - mean[vl * 4 + 1];
           xr[f++] = pz - mean[vl * 4 + 2];
         }
+        float dx = px, dy = py;  // what the distance decoration sees as x, y
         if (d.center) {  // coors are (b, z, y, x)
-          xr[f++] = px - ((float)cr.w * d.vs[0] + d.off[0]);
-          xr[f++] = py - ((float)cr.z * d.vs[1] + d.off[1]);
-          xr[f++] = pz - ((float)cr.y * d.vs[2] + d.off[2]);
+          const float cx = px - ((float)cr.w * d.vs[0] + d.off[0]);
+          const float cy = py - ((float)cr.z * d.vs[1] + d.off[1]);
+          xr[f++] = cx;
+          xr[f++] = cy;
+          if (!d.center_xy) xr[f++] = pz - ((float)cr.y * d.vs[2] + d.off[2]);
+          if (d.legacy) {
+            // the reference's f_center is a VIEW of features[:, :, :2] modified in place
+            // (pillar_encoder.py:124-130): raw x, y become the offsets too, after f_cluster was
+            // taken from the original values and before the distance is
+            xr[0] = cx, xr[1] = cy;
+            dx = cx, dy = cy;
+          }
         }
-        if (d.dist) xr[f++] = sqrtf(px * px + py * py + pz * pz);
+        if (d.dist) xr[f++] = sqrtf(dx * dx + dy * dy + pz * pz);
         if (d.mask && s >= np)
           for (int q = 0; q < cin; ++q) xr[q] = 0.0f;
       }
@@ -118,7 +134,8 @@ extern "C" int sf_vfe_layer(const float *inputs, int cin_raw, int max_points, co
   SF_CHECK_ARG(m_bound >= 0 && cin_raw >= 1 && max_points >= 1, "bad m_bound/cin/max_points");
   SF_CHECK_ARG(cout >= 1 && cout <= 256, "cout=%d not in [1,256]", cout);
   SF_CHECK_ARG(mode >= 0 && mode <= 2, "mode must be 0 (max), 1 (point-wise) or 2 (concat)");
-  SF_CHECK_ARG((decorate & ~15) == 0, "unknown decorate bits");
+  SF_CHECK_ARG((decorate & ~63) == 0, "unknown decorate bits");
+  SF_CHECK_ARG(!(decorate & 48) || (decorate & 2), "decorate bits 16 / 32 qualify bit 2");
   if (m_bound == 0) return SF_OK;
   SF_CHECK_ARG(inputs && weight && scale && shift && out, "NULL tensor pointer");
   SF_CHECK_ARG(!(decorate & 9) || num_points, "num_points is NULL");
@@ -130,11 +147,13 @@ extern "C" int sf_vfe_layer(const float *inputs, int cin_raw, int max_points, co
   d.center = (decorate >> 1) & 1;
   d.dist = (decorate >> 2) & 1;
   d.mask = (decorate >> 3) & 1;
+  d.center_xy = (decorate >> 4) & 1;
+  d.legacy = (decorate >> 5) & 1;
   for (int i = 0; i < 3; ++i) {
     d.vs[i] = voxel_size ? voxel_size[i] : 0.0f;
     d.off[i] = (voxel_size && coors_range) ? voxel_size[i] / 2 + coors_range[i] : 0.0f;
   }
-  const int cin = cin_raw + 3 * d.cluster + 3 * d.center + d.dist;
+  const int cin = cin_raw + 3 * d.cluster + (d.center_xy ? 2 : 3) * d.center + d.dist;
   const int tpv = cout <= 32 ? 32 : (cout <= 64 ? 64 : (cout <= 128 ? 128 : 256));
   const int vpb = 256 / tpv;
   const size_t lds = ((size_t)cin * cout + (size_t)vpb * max_points * cin + vpb * 4) * sizeof(float);

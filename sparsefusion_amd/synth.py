@@ -249,3 +249,18 @@ def second_fpn_state_dict(seed, in_channels, out_channels, upsample_strides,
         sd[f'deblocks.{i}.0.weight'] = rng.uniform(-bound, bound, shape).astype(np.float32)
         _bn2d_state(rng, sd, f'deblocks.{i}.1', co)
     return sd
+
+
+def pillar_feature_net_state_dict(seed, in_channels, feat_channels):
+    """Random-init state dict (numpy) for PillarFeatureNet(in_channels (decorated), feat_channels)
+    under the reference's key names (pfn_layers.N.linear.weight, pfn_layers.N.norm.*)."""
+    rng = np.random.default_rng(seed)
+    sd = {}
+    chans = [in_channels] + list(feat_channels)
+    for i in range(len(chans) - 1):
+        last = i == len(chans) - 2
+        cin, co = chans[i], (chans[i + 1] if last else chans[i + 1] // 2)
+        sd[f'pfn_layers.{i}.linear.weight'] = (rng.uniform(-1, 1, (co, cin)) *
+                                               math.sqrt(3.0 / cin)).astype(np.float32)
+        _bn2d_state(rng, sd, f'pfn_layers.{i}.norm', co)
+    return sd

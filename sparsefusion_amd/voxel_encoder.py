@@ -133,3 +133,82 @@ class HardVFE(nn.Module):
             else:
                 x = vfe(x)
         return x
+
+
+class PFNLayer(VFELayer):
+    """mmdet3d/models/voxel_encoders/utils.py:106-180: Linear(bias=False) -> BN1d -> ReLU -> max over
+    the points of a pillar; every layer but the last has out_channels // 2 units and concatenates
+    the repeated max.  Same attributes / state-dict keys (`linear`, `norm`, `units`, `last_vfe`)."""
+
+    def __init__(self, in_channels, out_channels, norm_cfg=dict(type='BN1d', eps=1e-3, momentum=0.01),
+                 last_layer=False, mode='max'):
+        assert mode in ['max', 'avg']
+        if mode != 'max':
+            raise NotImplementedError("PFNLayer mode 'avg' (the target configs use 'max')")
+        if not last_layer:
+            out_channels = out_channels // 2
+        super().__init__(in_channels, out_channels, norm_cfg=norm_cfg, max_out=True,
+                         cat_max=not last_layer)
+        self.name = 'PFNLayer'
+        self.last_vfe = last_layer
+        self.units = out_channels
+        self.mode = mode
+
+    def forward(self, inputs, num_voxels=None, aligned_distance=None):
+        if aligned_distance is not None:
+            raise NotImplementedError('aligned_distance is not used by PillarFeatureNet')
+        out = self._run(inputs)
+        return out.unsqueeze(1) if self.last_vfe else out     # (N, 1, C) as the reference's x_max
+
+
+@VOXEL_ENCODERS.register_module()
+class PillarFeatureNet(nn.Module):
+    """Drop-in for mmdet3d/models/voxel_encoders/pillar_encoder.py:11-150 (the voxel encoder of
+    configs/transfusion_nusc_pillar_L.py:157-165).  Decorations, padding mask and the first
+    PFNLayer run as ONE kernel (sf_vfe_layer with the pillar decorate bits)."""
+
+    def __init__(self, in_channels=4, feat_channels=(64, ), with_distance=False,
+                 with_cluster_center=True, with_voxel_center=True, voxel_size=(0.2, 0.2, 4),
+                 point_cloud_range=(0, -40, -3, 70.4, 40, 1),
+                 norm_cfg=dict(type='BN1d', eps=1e-3, momentum=0.01), mode='max', legacy=True):
+        super().__init__()
+        assert len(feat_channels) > 0
+        self.legacy = legacy
+        if with_cluster_center:
+            in_channels += 3
+        if with_voxel_center:
+            in_channels += 2
+        if with_distance:
+            in_channels += 1
+        self._with_distance = with_distance
+        self._with_cluster_center = with_cluster_center
+        self._with_voxel_center = with_voxel_center
+        self.fp16_enabled = False
+        self.in_channels = in_channels
+        chans = [in_channels] + list(feat_channels)
+        self.pfn_layers = nn.ModuleList([
+            PFNLayer(chans[i], chans[i + 1], norm_cfg=norm_cfg, last_layer=i == len(chans) - 2,
+                     mode=mode) for i in range(len(chans) - 1)])
+        self.vx = voxel_size[0]
+        self.vy = voxel_size[1]
+        self.x_offset = self.vx / 2 + point_cloud_range[0]
+        self.y_offset = self.vy / 2 + point_cloud_range[1]
+        self.voxel_size = list(voxel_size)
+        self.point_cloud_range = point_cloud_range
+
+    def forward(self, features, num_points, coors):
+        """features (N, M, C) f32, num_points (N,), coors (N, 4) (b, z, y, x) -> (N, feat_channels[-1])
+        (`.squeeze()`d like the reference's return value).  Unlike the reference's legacy mode the
+        caller's `features` tensor is left untouched (the in-place overwrite of its x / y columns,
+        pillar_encoder.py:124-130, happens on the kernel's staged copy)."""
+        deco = 8 | (1 if self._with_cluster_center else 0) | (4 if self._with_distance else 0)
+        if self._with_voxel_center:
+            deco |= 2 | 16 | (32 if self.legacy else 0)
+        x = features
+        for i, pfn in enumerate(self.pfn_layers):
+            if i == 0:
+                x = pfn._run(x, deco, num_points, coors, self.voxel_size,
+                             list(self.point_cloud_range))
+            else:
+                x = pfn._run(x)
+        return x.squeeze()
