@@ -57,7 +57,8 @@ class LidarBackbone:
 
     def __init__(self, voxel_layer_cfg, encoder, device, max_points, batch_size=1,
                  materialize_voxels=True, training=False, overlap=True, dtype='f32',
-                 voxel_encoder=None, bev_backbone=None, neck=None):
+                 voxel_encoder=None, bev_backbone=None, neck=None,
+                 heights_out_size_factor=None):
         """dtype 'f32': every layer on the exact-fp32 kernels.  'bf16' (BASELINE configs[2]): the
         first layer stays fp32 (raw metric coordinates need more than 8 significant bits), its
         output is cast to bf16, every later layer runs on the bf16 matrix cores with fp32
@@ -72,6 +73,16 @@ class LidarBackbone:
         if neck is not None and bev_backbone is None:
             raise ValueError('a neck needs a bev_backbone')
         self.bev_out = None
+        # heights_out_size_factor: also run SparseFusion's extract_voxel_heights on the voxels of
+        # the same voxelization (detectors/sparsefusion.py:73-112,159) and append the min / max
+        # height maps as two more channels of the neck's map (:127-130): the enqueue is then the
+        # whole of SparseFusionDetector.extract_pts_feat (:114-131)
+        self.osf = None if heights_out_size_factor is None else int(heights_out_size_factor)
+        if self.osf is not None:
+            if neck is None:
+                raise ValueError('the height channels are appended to the neck output')
+            materialize_voxels = True
+        self.min_height = self.max_height = None
         # voxel_encoder: None = the fused HardSimpleVFE mean (nuScenes config); a HardVFE module
         # (Waymo config, voxel_encoder.py:283-450) runs its VFE layers on the materialised voxels
         self.vfe = voxel_encoder
@@ -396,7 +407,27 @@ class LidarBackbone:
         if self.bev_backbone is None:
             return self.bev
         feats = self.bev_backbone(self.bev)
-        self.bev_out = self.neck(feats)[0] if self.neck is not None else feats
+        if self.neck is None:
+            self.bev_out = feats
+        elif self.osf is None:
+            self.bev_out = self.neck(feats)[0]
+        else:
+            # x[0] = cat([neck(x)[0], min_voxel_height[:, None], max_voxel_height[:, None]], 1)
+            # (sparsefusion.py:127-130) without the concatenation copy of the big map
+            gx, gy = s0['shape'][2], s0['shape'][1]
+            nx, ny = gx // self.osf, gy // self.osf
+            if self.min_height is None:
+                self.min_height = torch.empty((self.B, ny, nx), dtype=torch.float32, device=dev)
+                self.max_height = torch.empty_like(self.min_height)
+            chk(L.sf_voxel_heights(self.voxels.data_ptr(), s0['indices'].data_ptr(), c0,
+                                   s0['bound'], self.mp, self.F, self.B, ny, nx, self.osf,
+                                   self.min_height.data_ptr(), self.max_height.data_ptr(), st))
+            self.bev_out = self.neck(feats, extra_channels=2)[0]
+            c = self.bev_out.shape[1] - 2
+            if tuple(self.bev_out.shape[2:]) != (ny, nx):
+                raise RuntimeError(f'neck map {tuple(self.bev_out.shape[2:])} vs height map {(ny, nx)}')
+            self.bev_out[:, c].copy_(self.min_height)
+            self.bev_out[:, c + 1].copy_(self.max_height)
         return self.bev_out
 
     def __call__(self, points_list, voxel_features=None):

@@ -264,13 +264,17 @@ class SECONDFPN(nn.Module):
         k, s, p, up = _check_conv(layer)
         return ((x.shape[2] + 2 * p - k) // s + 1) * up, ((x.shape[3] + 2 * p - k) // s + 1) * up
 
-    def forward(self, x):
+    def forward(self, x, extra_channels=0):
+        """second_fpn.py:76-92.  `extra_channels` (not in the reference) reserves that many
+        uninitialised channels behind the concatenated ones, for a caller that appends maps of its
+        own (SparseFusionDetector.extract_pts_feat, detectors/sparsefusion.py:127-130)."""
         assert len(x) == len(self.in_channels)
         sizes = {self._out_hw(i, xi) for i, xi in enumerate(x)}
         if len(sizes) != 1:
             raise RuntimeError(f'deblock outputs differ in size: {sorted(sizes)} (torch.cat would fail)')
         (ho, wo), = sizes
-        out = torch.empty((x[0].shape[0], sum(self.out_channels), ho, wo), dtype=torch.float32,
+        out = torch.empty((x[0].shape[0], sum(self.out_channels) + int(extra_channels), ho, wo),
+                          dtype=torch.float32,
                           device=x[0].device)
         off = 0
         for i, deblock in enumerate(self.deblocks):

@@ -196,3 +196,36 @@ def test_lidar_backbone_with_second_and_neck_in_one_graph(dev, oracle):
                                     ncfg['upsample_strides'], True)[0]
     assert tuple(got.shape) == exp.shape
     assert_close(got.cpu().numpy(), exp, rtol=2e-4, atol_scale=2e-5)   # two fp32 stages chained
+
+
+def test_extract_pts_feat_in_one_enqueue(dev, oracle):
+    """SparseFusionDetector.extract_pts_feat (detectors/sparsefusion.py:114-131) as one enqueue:
+    the neck's map with the min / max voxel-height maps appended as channels C, C+1."""
+    from helpers import SMALL_RANGE, SMALL_SHAPE, SMALL_VOXEL, small_points
+    from sparsefusion_amd.pipeline import LidarBackbone
+    from sparsefusion_amd.voxel_heights import extract_voxel_heights
+    from test_gpu_conv import make_encoder
+    vl = dict(max_num_points=10, voxel_size=SMALL_VOXEL, max_voxels=(3000, 6000),
+              point_cloud_range=SMALL_RANGE)
+    enc, sd, cfg = make_encoder(dev, 5, 14)
+    bcfg = dict(in_channels=256, out_channels=[64, 128], layer_nums=[1, 1], layer_strides=[1, 2])
+    ncfg = dict(in_channels=[64, 128], out_channels=[32, 32], upsample_strides=[1, 2],
+                use_conv_for_no_stride=True)
+    _, _, bsd, nsd, second, neck = _modules(dev, bcfg, ncfg, 51)
+    frames = [small_points(600 + b, 3000 + 900 * b) for b in range(2)]
+    pts = [to_dev(p, dev) for p in frames]
+    bb = LidarBackbone(vl, enc, dev, max_points=8000, batch_size=2, bev_backbone=second, neck=neck,
+                       heights_out_size_factor=8)
+    with torch.no_grad():
+        got = bb(pts).clone()
+        res = bb.results()
+        want = neck(second(bb.bev))[0]
+        mn, mx = extract_voxel_heights(res['voxels'].contiguous(), res['coors'].contiguous(),
+                                       [SMALL_SHAPE[2], SMALL_SHAPE[1], SMALL_SHAPE[0] - 1], 8, 2)
+    assert tuple(got.shape) == (2, 66, 20, 20)
+    assert torch.equal(got[:, :64], want)
+    assert torch.equal(got[:, 64], mn) and torch.equal(got[:, 65], mx)
+    o_mn, o_mx = oracle.voxel_heights(res['voxels'].cpu().numpy(), res['coors'].cpu().numpy(), 2,
+                                      [SMALL_SHAPE[2], SMALL_SHAPE[1], SMALL_SHAPE[0] - 1], 8)
+    assert np.array_equal(got[:, 64].cpu().numpy(), o_mn)
+    assert np.array_equal(got[:, 65].cpu().numpy(), o_mx)
