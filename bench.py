@@ -221,11 +221,20 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', 0))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
-    dev = torch.device('cuda', local)
+    # One rank per GPU.  SF_BENCH_BACKEND=gloo is a REHEARSAL switch for a box with fewer GPUs than
+    # ranks (ranks then share devices, scalars cross ranks over gloo); the driver's runs use RCCL.
+    backend = os.environ.get('SF_BENCH_BACKEND', 'nccl')
+    ndev = torch.cuda.device_count()
+    if backend == 'nccl' and local >= ndev:
+        raise SystemExit(f'LOCAL_RANK {local} but {ndev} GPU(s) visible')
+    dev = torch.device('cuda', local % max(ndev, 1))
     torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     gen = synth.nuscenes_frame if args.workload == 'nusc' else synth.waymo_frame
     B = args.batch

@@ -17,6 +17,8 @@ def frames_for_rank(rank, world, n_frames):
 def max_over_ranks(value, device=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return float(value)
+    if dist.get_backend() != 'nccl':
+        device = None          # gloo (CPU tests, rehearsals) reduces host tensors
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
