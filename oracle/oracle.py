@@ -490,6 +490,94 @@ def sparse_encoder_forward(state_dict, voxel_features, coors, batch_size, sparse
     return bev
 
 
+# ---------------------------------------------------------------- SparseUNet wiring
+
+def indice_inverse_conv(features, filters_kio, pairs, num, n_out):
+    """Fsp.indice_inverse_conv (ops/spconv/functional.py:39-55 -> indiceConv with inverse = 1,
+    spconv_ops.h:319-348): rows are gathered through indicePairs[k][1] and scattered through
+    indicePairs[k][0], filter k unchanged -- the forward loop on the swapped pair columns."""
+    return indice_conv(features, filters_kio, np.ascontiguousarray(_i32(pairs)[:, ::-1, :]), num,
+                       n_out, False)
+
+
+def sparse_unet_forward(sd, voxel_features, coors, batch_size, sparse_shape, in_channels,
+                        base_channels=16, output_channels=128,
+                        encoder_channels=((16,), (32, 32, 32), (64, 64, 64), (64, 64, 64)),
+                        encoder_paddings=((1,), (1, 1, 1), (1, 1, 1), ((0, 1, 1), 1, 1)),
+                        decoder_channels=((64, 64, 64), (64, 64, 32), (32, 32, 16), (16, 16, 16)),
+                        decoder_paddings=((1, 0), (1, 0), (0, 0), (0, 1)), bn_eps=1e-3):
+    """SparseUNet.forward (mmdet3d/models/middle_encoders/sparse_unet.py:96-169) on the CPU oracle,
+    post-activate order.  Returns (spatial_features, seg_features, seg_indices)."""
+    cache = {}
+
+    def rulebook(key, idx, shape, ksize, stride, padding, subm):
+        if key not in cache:   # conv.py:147-172: keyed rulebooks are built once and reused
+            outids, pairs, num, oshape = get_indice_pairs(idx, batch_size, shape, ksize, stride,
+                                                          padding, 1, subm)
+            cache[key] = (outids, idx, pairs, num, list(shape), list(oshape))
+        return cache[key]
+
+    def convmodule(prefix, feats, idx, shape, cin, cout, ksize, stride, padding, subm, key,
+                   inverse=False):
+        w = weight_to_kio(sd[f'{prefix}.0.weight'], ksize, cin, cout)
+        if inverse:
+            _, in_idx, pairs, num, in_shape, _ = cache[key]
+            y = indice_inverse_conv(feats, w, pairs, num, in_idx.shape[0])
+            idx, shape = in_idx, in_shape
+        else:
+            outids, _, pairs, num, _, oshape = rulebook(key, idx, shape, ksize, stride, padding, subm)
+            y = indice_conv(feats, w, pairs, num, outids.shape[0], subm)
+            idx, shape = outids, oshape
+        return bn_act(y, _bn(sd, f'{prefix}.1'), bn_eps, None, True), idx, list(shape)
+
+    feats, idx, shape = _f32(voxel_features), _i32(coors), list(sparse_shape)
+    feats, idx, shape = convmodule('conv_input', feats, idx, shape, in_channels, base_channels, 3, 1,
+                                   1, True, 'subm1')
+    cin = base_channels
+    enc = []
+    for i, blocks in enumerate(encoder_channels):                          # :191-235
+        for j, cout in enumerate(tuple(blocks)):
+            p = f'encoder_layers.encoder_layer{i + 1}.{j}'
+            pad = tuple(encoder_paddings[i])[j]
+            if i != 0 and j == 0:
+                feats, idx, shape = convmodule(p, feats, idx, shape, cin, cout, 3, 2, pad, False,
+                                               f'spconv{i + 1}')
+            else:
+                feats, idx, shape = convmodule(p, feats, idx, shape, cin, cout, 3, 1, pad, True,
+                                               f'subm{i + 1}')
+            cin = cout
+        enc.append((feats, idx, shape))
+    y, oidx, oshape = convmodule('conv_out', feats, idx, shape, cin, output_channels, (3, 1, 1),
+                                 (2, 1, 1), 0, False, 'spconv_down2')
+    spatial = dense_bev(y, oidx, int(batch_size), oshape)
+    stages = len(decoder_channels)
+    bottom = enc[-1][0]
+    for i, (c_lat, c_merge, c_up) in enumerate(decoder_channels):          # :133-169, :237-292
+        level = stages - i
+        lat, lidx, lshape = enc[level - 1]
+        outids, _, pairs, num, _, _ = rulebook(f'subm{level}', lidx, lshape, 3, 1, 1, True)
+        p = f'lateral_layer{level}'                                         # SparseBasicBlock
+        h = indice_conv(lat, weight_to_kio(sd[f'{p}.conv1.weight'], 3, cin, c_lat), pairs, num,
+                        outids.shape[0], True)
+        h = bn_act(h, _bn(sd, f'{p}.bn1'), bn_eps, None, True)
+        h = indice_conv(h, weight_to_kio(sd[f'{p}.conv2.weight'], 3, c_lat, c_lat), pairs, num,
+                        outids.shape[0], True)
+        h = bn_act(h, _bn(sd, f'{p}.bn2'), bn_eps, lat, True)
+        cat = np.concatenate([bottom, h], axis=1)                           # :164
+        merged, _, _ = convmodule(f'merge_layer{level}', cat, lidx, lshape, cin * 2, c_merge, 3, 1,
+                                  decoder_paddings[i][0], True, f'subm{level}')
+        red = cat.reshape(cat.shape[0], c_merge, -1).sum(axis=2)            # reduce_channel :171-189
+        x = (merged + red).astype(np.float32)                               # :167
+        if level != 1:
+            bottom, idx, shape = convmodule(f'upsample_layer{level}', x, lidx, lshape, cin, c_up, 3,
+                                            1, 0, False, f'spconv{level}', inverse=True)
+        else:
+            bottom, idx, shape = convmodule(f'upsample_layer{level}', x, lidx, lshape, cin, c_up, 3,
+                                            1, decoder_paddings[i][1], True, 'subm1')
+        cin = c_up
+    return spatial, bottom, idx
+
+
 # ------------------------------------------------------------------ BEV backbone / neck (SURVEY 8f-3)
 # The reference's SECOND / SECONDFPN are chains of torch modules (nn.Conv2d, nn.ConvTranspose2d,
 # nn.BatchNorm2d(eps=1e-3), nn.ReLU), so the reference's CPU arithmetic IS torch's CPU kernels: the

@@ -70,12 +70,33 @@ def build_norm_layer(cfg, num_features, postfix=''):
     return 'bn' + str(postfix), layer
 
 
+def _populate():
+    """Import the modules whose classes register themselves (mmdet3d does this in
+    mmdet3d/models/__init__.py), so a `type=` string resolves whatever was imported before."""
+    from . import (pillar_scatter, second, sparse_encoder, sparse_unet, spconv,  # noqa: F401
+                   voxel_encoder)
+
+
 def build_middle_encoder(cfg):
+    _populate()
     return MIDDLE_ENCODERS.build(cfg)
 
 
 def build_voxel_encoder(cfg):
+    _populate()
     return VOXEL_ENCODERS.build(cfg)
+
+
+def build_backbone(cfg):
+    _populate()
+    from .second import BACKBONES
+    return BACKBONES.build(cfg)
+
+
+def build_neck(cfg):
+    _populate()
+    from .second import NECKS
+    return NECKS.build(cfg)
 
 
 def register_with_mmcv():

@@ -68,14 +68,16 @@ def make_sparse_convmodule(in_channels, out_channels, kernel_size, indice_key, s
     """sparse_block.py:142-204: SparseSequential of conv / norm / ReLU in `order`."""
     assert isinstance(order, tuple) and len(order) <= 3
     assert set(order) | {'conv', 'norm', 'act'} == {'conv', 'norm', 'act'}
-    if 'Inverse' in conv_type:
-        raise NotImplementedError('inverse convolutions are outside the hot path')
     layers = []
     for layer in order:
         if layer == 'conv':
-            layers.append(build_conv_layer(dict(type=conv_type, indice_key=indice_key), in_channels,
-                                           out_channels, kernel_size, stride=stride,
-                                           padding=padding, bias=False))
+            if 'Inverse' in conv_type:      # sparse_block.py:191-198: no stride / padding argument
+                layers.append(build_conv_layer(dict(type=conv_type, indice_key=indice_key),
+                                               in_channels, out_channels, kernel_size, bias=False))
+            else:
+                layers.append(build_conv_layer(dict(type=conv_type, indice_key=indice_key),
+                                               in_channels, out_channels, kernel_size,
+                                               stride=stride, padding=padding, bias=False))
         elif layer == 'norm':
             layers.append(build_norm_layer(norm_cfg, out_channels)[1])
         elif layer == 'act':

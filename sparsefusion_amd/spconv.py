@@ -84,6 +84,30 @@ class Rulebook:
     def k_first(self):
         return (self.K - 1) // 2 if self.subm else -1
 
+    def inverted(self):
+        """Rulebook of the coupled inverse convolution (SparseInverseConv3d, conv.py:147-152 /
+        spconv_ops.h:319-348 with inverse = 1): every pair (in, out) of offset k becomes (out, in)
+        of the same offset, the output set is this rulebook's INPUT set.  A strided convolution
+        reaches an input through one offset from at most one output, so the swapped pairs form a
+        neighbour table again (built from the exported pairs; the kernels are the forward ones)."""
+        if getattr(self, '_inverse', None) is None:
+            if self.subm:
+                raise RuntimeError('an inverse convolution couples with a SparseConv3d, not a SubM one')
+            L = _lib.lib()
+            pairs, num = self.indice_pairs()
+            swapped = pairs[:, [1, 0], :].contiguous()
+            n_new_out = self.in_coords.n
+            stride = nbr_stride(n_new_out)
+            nbr = torch.empty((self.K, stride), dtype=torch.int32, device=pairs.device)
+            _lib.check(L.sf_indice_pairs_to_table(swapped.data_ptr(), num.data_ptr(), self.K,
+                                                  swapped.shape[2], n_new_out, nbr.data_ptr(), stride,
+                                                  _lib.stream(pairs.device)))
+            inv = Rulebook(nbr, self.K, self.out_coords, self.in_coords, self.ksize, self.stride,
+                           self.padding, False)
+            inv._keep = swapped
+            self._inverse = inv
+        return self._inverse
+
     def indice_pairs(self):
         """(indice_pairs (K,2,N_in) int32, indice_num (K,) int32) in the reference layout."""
         if self._pairs is None:
@@ -436,8 +460,8 @@ class SparseConvolution(SparseModule):
         super().__init__()
         if ndim != 3:
             raise NotImplementedError('only 3-D sparse convolution is on the hot path')
-        if groups != 1 or transposed or inverse:
-            raise NotImplementedError('groups/transposed/inverse convolution is out of scope')
+        if groups != 1 or transposed:
+            raise NotImplementedError('groups/transposed convolution is out of scope')
         self.ndim = ndim
         self.in_channels = in_channels
         self.out_channels = out_channels
@@ -487,6 +511,12 @@ class SparseConvolution(SparseModule):
 
     def rulebook_for(self, input):
         datas = input.find_indice_pair(self.indice_key)
+        if self.inverse:   # conv.py:147-152: the couple conv's rulebook, pairs swapped
+            assert datas is not None and self.indice_key is not None
+            rb = datas.rulebook
+            assert rb.K == int(np.prod(self.kernel_size)), \
+                'inverse conv must have same kernel size as its couple conv'
+            return rb.inverted()
         if self.indice_key is not None and datas is not None:
             return datas.rulebook
         rb = build_rulebook(input.coords(), self.kernel_size, self.stride, self.padding,
@@ -524,6 +554,15 @@ class SparseConv3d(SparseConvolution):
                  groups=1, bias=True, indice_key=None):
         super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation,
                          groups, bias, indice_key=indice_key)
+
+
+class SparseInverseConv3d(SparseConvolution):
+    """conv.py:359-374: the inverse of the SparseConv3d that registered `indice_key`; restores that
+    convolution's input index set (rows in the same order)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, indice_key, bias=True):
+        super().__init__(3, in_channels, out_channels, kernel_size, bias=bias, inverse=True,
+                         indice_key=indice_key)
 
 
 class SubMConv3d(SparseConvolution):
@@ -603,3 +642,4 @@ from .registry import CONV_LAYERS  # noqa: E402
 
 CONV_LAYERS.register_module('SparseConv3d', module=SparseConv3d, force=True)
 CONV_LAYERS.register_module('SubMConv3d', module=SubMConv3d, force=True)
+CONV_LAYERS.register_module('SparseInverseConv3d', module=SparseInverseConv3d, force=True)

@@ -264,3 +264,32 @@ def pillar_feature_net_state_dict(seed, in_channels, feat_channels):
                                                math.sqrt(3.0 / cin)).astype(np.float32)
         _bn2d_state(rng, sd, f'pfn_layers.{i}.norm', co)
     return sd
+
+
+def sparse_unet_state_dict(seed, in_channels, base_channels=16, output_channels=128,
+                           encoder_channels=((16,), (32, 32, 32), (64, 64, 64), (64, 64, 64)),
+                           decoder_channels=((64, 64, 64), (64, 64, 32), (32, 32, 16), (16, 16, 16)),
+                           **_):
+    """Random-init state dict (numpy, spconv-2 filter layout) for SparseUNet under the reference's
+    key names: the conv_module encoder plus lateral_layerN.{conv1,bn1,conv2,bn2},
+    merge_layerN.{0,1}, upsample_layerN.{0,1} (sparse_unet.py:237-292)."""
+    sd = encoder_state_dict(seed, in_channels, base_channels=base_channels,
+                            output_channels=output_channels, encoder_channels=encoder_channels,
+                            block_type='conv_module')
+    rng = np.random.default_rng(seed + 1)
+
+    def conv(wkey, bn, ci, co):
+        w = _he_uniform(rng, (3, 3, 3, ci, co))
+        sd[wkey] = np.ascontiguousarray(np.transpose(w, (4, 0, 1, 2, 3)))
+        _bn2d_state(rng, sd, bn, co)
+
+    cin = tuple(encoder_channels[-1])[-1]
+    n = len(decoder_channels)
+    for i, (c_lat, c_merge, c_up) in enumerate(decoder_channels):
+        lv = n - i
+        conv(f'lateral_layer{lv}.conv1.weight', f'lateral_layer{lv}.bn1', cin, c_lat)
+        conv(f'lateral_layer{lv}.conv2.weight', f'lateral_layer{lv}.bn2', c_lat, c_lat)
+        conv(f'merge_layer{lv}.0.weight', f'merge_layer{lv}.1', cin * 2, c_merge)
+        conv(f'upsample_layer{lv}.0.weight', f'upsample_layer{lv}.1', cin, c_up)
+        cin = c_up
+    return sd
