@@ -140,6 +140,7 @@ def time_layers(bb, pts, vf, iters=5, busy=None):
     shim = Shim()
     shim.__dict__['sf_sparse_conv_f32'] = timed(L.sf_sparse_conv_f32)
     shim.__dict__['sf_sparse_conv_bf16'] = timed(L.sf_sparse_conv_bf16)
+    shim.__dict__['sf_sparse_conv_f32_ordered'] = timed(L.sf_sparse_conv_f32_ordered)
     acc = np.zeros(nl)
     old = bb.L
     bb.L = shim
@@ -173,7 +174,7 @@ def measured_traffic(cin, cout, bf16=False):
     with open(path) as f:
         table = json.load(f)
     pat = re.compile((r'conv_bf16_(tile|direct)_kernel<%d, %d,' if bf16 else
-                      r'sparse_conv_f32(_wide|_direct)?_kernel<%d, %d,') % (cin, cout))
+                      r'(sparse_conv_f32(_wide|_direct)?|conv_f32_ordered)_kernel<%d, %d,') % (cin, cout))
     hits = [v for k, v in table.items() if pat.match(k)]
     if not hits:
         return None
@@ -321,15 +322,13 @@ def main():
             nb = max(2, int(np.ceil(12.0 / max(elapsed / args.steps * 1e3, 1e-3))))   # ~12 ms
 
             def keep_busy(fi):
-                """The conditions of the timed region around the timed eager frame: the same
-                frame's graph replayed ahead of it on this stream (clocks up, host ahead of the
-                GPU), and the other lanes replaying theirs beside it (frames in flight)."""
+                """The same frame's graph replayed ahead of the timed eager frame on this stream:
+                clocks up, host ahead of the GPU.  The other lanes stay idle: a launch is timed
+                with the GPU to itself, which is also what a rocprofv3 kernel trace reports (the
+                trace of this run agrees within 2 %; with the other lane replaying beside, the
+                same launches read 230 us instead of 175 because they share the CUs)."""
                 for _ in range(nb):
                     steps[0][1][fi]()
-                for st_, fns_ in steps[1:]:
-                    with torch.cuda.stream(st_):
-                        for _ in range(nb + 2):
-                            fns_[fi]()
 
             ms, work, counts = None, None, None
             for fi, fr in enumerate(frames):
@@ -382,7 +381,9 @@ def main():
                 roofline['kernel'] = f'conv_bf16_kernel<{max(dom[0], 16)},{dom[1]}>'
                 roofline['traffic'] = measured_traffic(max(dom[0], 16), dom[1], True)
             else:
-                roofline['kernel'] = f'sparse_conv_f32_kernel<{dom[0] if dom[0] > 8 else 8},{dom[1]}>'
+                ordered = any(getattr(l, 'ordered', False) and (l.cin, l.cout) == dom[:2] for l in bb.layers)
+                roofline['kernel'] = (f'conv_f32_ordered_kernel<{dom[0]},{dom[1]}>' if ordered else
+                                      f'sparse_conv_f32_kernel<{dom[0] if dom[0] > 8 else 8},{dom[1]}>')
                 roofline['traffic'] = measured_traffic(dom[0] if dom[0] > 8 else 8, dom[1])
             roofline['launches_per_frame'] = gd['launches']
             roofline['avg_launch_us'] = round(avg_s * 1e6, 2)

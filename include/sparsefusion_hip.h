@@ -254,6 +254,35 @@ SF_API int sf_sparse_conv_bf16(const void *features_in, int n_in_bound, int cin_
                                const float *shift, const void *residual, int relu, void *out,
                                int out_is_f32, const int *n_out_dev, int n_out_bound, void *stream);
 
+/* ---- the same convolution over mask-ordered rows (csrc/spconv_f32_ordered.hip) ---- */
+
+/* Workspace bytes of sf_row_order_by_mask for up to n_bound output rows. */
+SF_API size_t sf_row_order_workspace(int n_bound);
+
+/* row_order (n_bound) i32 = the output rows of a neighbour table sorted (stably) by their K-bit
+ * neighbour mask (bit k set <=> nbr[k][row] >= 0); entries [*n_dev, n_bound) hold the unused rows.
+ * No reference counterpart: the reference's rulebook has no row order of its own (pairs are
+ * listed per offset, spconv_ops.h:55-59); this is the schedule sf_sparse_conv_f32_ordered runs
+ * its tiles in, built once per rulebook and shared by every layer that uses it. */
+SF_API int sf_row_order_by_mask(const int *nbr, int nbr_stride, int K, const int *n_dev, int n_bound,
+                                int *row_order, void *workspace, size_t workspace_bytes,
+                                void *stream);
+
+/* sf_sparse_conv_f32 (same reference interface: indice_conv_fp32 / indice_subm_conv,
+ * spconv_ops.h:260-361, + the fused BN / residual / ReLU tail) with a different work
+ * decomposition: tiles of 64 entries of row_order (NULL = natural order), no pair compaction,
+ * sums kept in the MFMA accumulators, (offset, 16-row block) products without a partner skipped.
+ * Results are fp32 FMA chains in the reference's order (centre offset first for SubM, then
+ * offsets ascending), independent of row_order.  features_in is (n_in_bound, cin_padded) f32
+ * with cin_padded in {16, 32, 64, 128}: n_in_bound rows must be addressable (the gather is bounds
+ * checked against it; table < 4 GiB). */
+SF_API int sf_sparse_conv_f32_ordered(const float *features_in, int n_in_bound, int cin_padded,
+                                      const int *nbr, int nbr_stride, int K, int k_first,
+                                      const int *row_order, const float *w_packed, int cout,
+                                      const float *scale, const float *shift, const float *residual,
+                                      int relu, float *out, const int *n_out_dev, int n_out_bound,
+                                      void *stream);
+
 /* ------------------------------------------------------------------ dense BEV -------- */
 
 /* Replaces SparseConvTensor.dense() + view (mmdet3d/ops/spconv/structure.py:55-64,

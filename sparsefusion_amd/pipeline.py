@@ -25,7 +25,7 @@ from .sparse_encoder import SparseEncoder
 
 class _Layer:
     __slots__ = ('conv', 'bn', 'relu', 'residual_from', 'rb', 'cin', 'cout', 'packed', 'scale',
-                 'shift', 'in_buf', 'out_buf', 'bf16', 'out_dtype')
+                 'shift', 'in_buf', 'out_buf', 'bf16', 'out_dtype', 'ordered')
 
 
 def _flatten_encoder(enc):
@@ -174,6 +174,15 @@ class LidarBackbone:
             nb = spconv.nbr_stride(self.sets[rb['dst']]['bound'])
             rb['nbr'] = i32(rb['K'], nb)
             rb['stride'] = nb
+        # row order by neighbour mask for the rulebooks whose fp32 layers run on the ordered kernel
+        for lay in self.layers:
+            lay.ordered = (not lay.bf16) and spconv.use_ordered(L.sf_conv_padded_cin(lay.cin), lay.cout)
+            if lay.ordered and 'order' not in lay.rb:
+                nb_rows = self.sets[lay.rb['dst']]['bound']
+                lay.rb['order'] = i32(nb_rows)
+                lay.rb['order_ws_bytes'] = L.sf_row_order_workspace(nb_rows)
+                lay.rb['order_ws'] = torch.empty(lay.rb['order_ws_bytes'], dtype=torch.uint8,
+                                                 device=dev)
         ws = 0
         for rb in self.rulebooks:
             if not rb['subm']:
@@ -321,6 +330,7 @@ class LidarBackbone:
                     dst['vals'].data_ptr(), dst['cap'], dst['indices'].data_ptr(), dst['bound'],
                     n_dst, ovf, rb['nbr'].data_ptr(), rb['stride'], self.rb_ws.data_ptr(),
                     self.rb_ws_bytes, ss))
+                self._row_order(rb, n_dst, dst['bound'], ss)
                 if fork and ri > 0:
                     e = torch.cuda.Event()
                     e.record(side)
@@ -331,6 +341,7 @@ class LidarBackbone:
                 _lib.i3(rb['ks']), _lib.i3(rb['st']), _lib.i3(rb['pd']), src['keys'].data_ptr(),
                 src['vals'].data_ptr(), src['cap'], 1 if rb['subm'] else 0, rb['nbr'].data_ptr(),
                 rb['stride'], ss))
+            self._row_order(rb, n_dst, dst['bound'], ss)
             if fork and ri > 0:
                 e = torch.cuda.Event()
                 e.record(side)
@@ -385,6 +396,12 @@ class LidarBackbone:
                     lay.shift.data_ptr(), res_ptr, 1 if lay.relu else 0, out.data_ptr(),
                     1 if lay.out_dtype == torch.float32 else 0, c0 + 4 * rb['dst'],
                     self.sets[rb['dst']]['bound'], st))
+            elif lay.ordered:
+                chk(L.sf_sparse_conv_f32_ordered(
+                    x.data_ptr(), x.shape[0], cp, rb['nbr'].data_ptr(), rb['stride'], rb['K'],
+                    k_first, rb['order'].data_ptr(), lay.packed.data_ptr(), lay.cout,
+                    lay.scale.data_ptr(), lay.shift.data_ptr(), res_ptr, 1 if lay.relu else 0,
+                    out.data_ptr(), c0 + 4 * rb['dst'], self.sets[rb['dst']]['bound'], st))
             else:
                 chk(L.sf_sparse_conv_f32(
                     x.data_ptr(), cp, rb['nbr'].data_ptr(), rb['stride'], rb['K'], k_first,
@@ -429,6 +446,13 @@ class LidarBackbone:
             self.bev_out[:, c].copy_(self.min_height)
             self.bev_out[:, c + 1].copy_(self.max_height)
         return self.bev_out
+
+    def _row_order(self, rb, n_dev, n_bound, stream):
+        """Mask order of the rulebook's output rows, right behind its neighbour table (same stream)."""
+        if 'order' in rb:
+            _lib.check(self.L.sf_row_order_by_mask(
+                rb['nbr'].data_ptr(), rb['stride'], rb['K'], n_dev, n_bound, rb['order'].data_ptr(),
+                rb['order_ws'].data_ptr(), rb['order_ws_bytes'], stream))
 
     def __call__(self, points_list, voxel_features=None):
         return self.enqueue(points_list, voxel_features)

@@ -126,6 +126,22 @@ class Rulebook:
         return self._pairs
 
 
+_ORDERED_DEFAULT = ''      # filled in from measurements (tools/ab_ordered.py, bench.py)
+
+
+def use_ordered(cin_padded, cout):
+    """Whether an fp32 layer of this shape runs on the mask-ordered kernel
+    (sf_sparse_conv_f32_ordered) instead of the pair-compacting / direct ones.  SF_CONV_ORDERED
+    overrides: 'all', 'none' or a comma list of CINxCOUT shapes."""
+    import os
+    sel = os.environ.get('SF_CONV_ORDERED', _ORDERED_DEFAULT).strip().lower()
+    if cin_padded < 16 or sel in ('', 'none', '0'):
+        return False
+    if sel in ('all', '1'):
+        return True
+    return f'{cin_padded}x{cout}' in sel.split(',')
+
+
 def nbr_stride(rows):
     """Column stride (in rows) of a neighbour table for `rows` output rows: a multiple of 1024
     rows plus 64, so that the K columns a tile reads together start 256 bytes apart modulo 4 KiB

@@ -1,0 +1,125 @@
+"""sf_row_order_by_mask + sf_sparse_conv_f32_ordered (csrc/spconv_f32_ordered.hip): the mask-ordered,
+register-accumulator decomposition of the fp32 sparse convolution, against the CPU oracle
+(indiceConv restatement) and against sf_sparse_conv_f32 on the same rulebook.  fp32 bar of the
+other conv tests: |a-b| <= 1e-4|b| + 1e-5 max|b|."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import SMALL_RANGE, SMALL_SHAPE, SMALL_VOXEL, assert_close, small_points, to_dev
+from sparsefusion_amd import _lib, spconv
+
+pytestmark = pytest.mark.gpu
+
+
+def _coords(oracle, seed, n, batch=1):
+    cs = [oracle.hard_voxelize(small_points(seed + b, n, 4), SMALL_VOXEL, SMALL_RANGE, 5, 20000)[1]
+          for b in range(batch)]
+    return oracle.batch_coors(cs)
+
+
+def _row_order(rb, dev):
+    L = _lib.lib()
+    n = rb.out_coords.n
+    order = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    wsb = L.sf_row_order_workspace(max(n, 1))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    _lib.check(L.sf_row_order_by_mask(rb.nbr.data_ptr(), rb.nbr.shape[1], rb.K, None, n,
+                                      order.data_ptr(), ws.data_ptr(), wsb, _lib.stream(dev)))
+    return order
+
+
+@pytest.mark.parametrize('subm,ks,st,pd', [(True, 3, 1, 1), (False, 3, 2, 1), (False, (3, 1, 1), (2, 1, 1), 0)])
+def test_row_order_is_a_mask_sorted_permutation(dev, oracle, subm, ks, st, pd):
+    coors = _coords(oracle, 40, 6000, 2)
+    cs = spconv.CoordSet(to_dev(coors, dev), SMALL_SHAPE, 2)
+    rb = spconv.build_rulebook(cs, ks, st, pd, 1, subm)
+    order = _row_order(rb, dev).cpu().numpy()
+    n = rb.out_coords.n
+    assert np.array_equal(np.sort(order[:n]), np.arange(n))
+    nbr = rb.nbr[:, :n].cpu().numpy()
+    mask = ((nbr >= 0).astype(np.int64) << np.arange(rb.K)[:, None]).sum(0)
+    m = mask[order[:n]]
+    assert np.all(np.diff(m) >= 0)                                   # sorted by mask
+    same = np.diff(m) == 0
+    assert np.all(np.diff(order[:n])[same] > 0)                       # stable inside a mask
+
+
+@pytest.mark.parametrize('cin,cout,subm,ks,st,pd', [
+    (16, 16, True, 3, 1, 1), (16, 32, False, 3, 2, 1), (32, 32, True, 3, 1, 1),
+    (32, 64, False, 3, 2, 1), (64, 64, True, 3, 1, 1), (64, 128, False, 3, 2, (0, 1, 1)),
+    (128, 128, True, 3, 1, 1), (128, 128, False, (3, 1, 1), (2, 1, 1), 0), (128, 64, True, 3, 1, 1)])
+@pytest.mark.parametrize('ordered', [True, False])
+def test_ordered_conv_matches_oracle(dev, oracle, cin, cout, subm, ks, st, pd, ordered):
+    rng = np.random.default_rng(cin + cout)
+    coors = _coords(oracle, 50 + cin, 5000)
+    n_in = coors.shape[0]
+    feats = rng.normal(0, 1, (n_in, cin)).astype(np.float32)
+    tri = lambda v: list(v) if isinstance(v, (tuple, list)) else [v] * 3
+    K = int(np.prod(tri(ks)))
+    w = (rng.uniform(-1, 1, (K, cin, cout)) * np.sqrt(3.0 / (min(K, 9) * cin))).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = rng.normal(0, 0.1, cout).astype(np.float32)
+    outids, pairs, num, _ = oracle.get_indice_pairs(coors, 1, SMALL_SHAPE, ks, st, pd, 1, subm)
+    n_out = outids.shape[0]
+    res = rng.normal(0, 1, (n_out, cout)).astype(np.float32) if subm else None
+    y = oracle.indice_conv(feats, w, pairs, num, n_out, subm)
+    expect = y * scale + shift + (res if res is not None else 0)
+    expect = np.maximum(expect, 0).astype(np.float32)
+    cs = spconv.CoordSet(to_dev(coors, dev), SMALL_SHAPE, 1)
+    rb = spconv.build_rulebook(cs, ks, st, pd, 1, subm)
+    assert np.array_equal(rb.out_coords.indices[:n_out].cpu().numpy(), outids)
+    L = _lib.lib()
+    d_feats, d_w = to_dev(feats, dev), spconv.pack_filters(to_dev(w, dev))
+    d_scale, d_shift = to_dev(scale, dev), to_dev(shift, dev)
+    d_res = to_dev(res, dev) if res is not None else None
+    order = _row_order(rb, dev) if ordered else None
+    out = torch.full((n_out, cout), np.nan, dtype=torch.float32, device=dev)
+    _lib.check(L.sf_sparse_conv_f32_ordered(
+        d_feats.data_ptr(), n_in, cin, rb.nbr.data_ptr(), rb.nbr.shape[1], rb.K, rb.k_first,
+        order.data_ptr() if ordered else None, d_w.data_ptr(), cout, d_scale.data_ptr(),
+        d_shift.data_ptr(), _lib.ptr(d_res), 1, out.data_ptr(), None, n_out, _lib.stream(dev)))
+    torch.cuda.synchronize()
+    assert_close(out.cpu().numpy(), expect)
+    ref = torch.empty_like(out)
+    _lib.check(L.sf_sparse_conv_f32(d_feats.data_ptr(), cin, rb.nbr.data_ptr(), rb.nbr.shape[1], rb.K,
+                                    rb.k_first, d_w.data_ptr(), cout, d_scale.data_ptr(),
+                                    d_shift.data_ptr(), _lib.ptr(d_res), 1, ref.data_ptr(), None,
+                                    n_out, _lib.stream(dev)))
+    torch.cuda.synchronize()
+    assert_close(out.cpu().numpy(), ref.cpu().numpy())
+
+
+def test_pipeline_with_the_ordered_kernel(dev, oracle, monkeypatch):
+    """LidarBackbone with every eligible layer on the ordered kernel (SF_CONV_ORDERED=all), device
+    row counts, captured in a HIP graph: BEV map against the oracle."""
+    from sparsefusion_amd.pipeline import LidarBackbone
+    from test_gpu_conv import make_encoder
+    from test_gpu_pipeline import VL, oracle_bev
+    monkeypatch.setenv('SF_CONV_ORDERED', 'all')
+    enc, sd, cfg = make_encoder(dev, 5, 21)
+    frames = [small_points(700 + b, 3000 + 800 * b) for b in range(2)]
+    pts = [to_dev(p, dev) for p in frames]
+    bb = LidarBackbone(VL, enc, dev, max_points=8000, batch_size=2)
+    assert any(l.ordered for l in bb.layers) and not bb.layers[0].ordered
+    with torch.no_grad():
+        g = bb.capture(pts)
+        g.replay()
+        torch.cuda.synchronize()
+        bev = bb.bev.clone()
+    assert bb.results()['overflow'] == 0
+    expect, _, _ = oracle_bev(oracle, sd, cfg, frames, 10, 6000)
+    assert_close(bev.cpu().numpy(), expect, 1e-4)
+
+
+def test_bad_arguments(dev):
+    L = _lib.lib()
+    x = torch.zeros(64, 16, device=dev)
+    nbr = torch.full((27, 64), -1, dtype=torch.int32, device=dev)
+    assert L.sf_sparse_conv_f32_ordered(x.data_ptr(), 64, 8, nbr.data_ptr(), 64, 27, 13, None,
+                                        x.data_ptr(), 16, None, None, None, 0, x.data_ptr(), None, 64,
+                                        None) < 0
+    assert b'cin_padded' in L.sf_last_error()
+    assert L.sf_row_order_by_mask(nbr.data_ptr(), 64, 27, None, 64, x.data_ptr(), x.data_ptr(), 16,
+                                  None) < 0
+    assert b'workspace' in L.sf_last_error()
