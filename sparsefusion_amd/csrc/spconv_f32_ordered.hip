@@ -169,36 +169,54 @@ conv_f32_ordered_kernel(const float *__restrict__ feat, unsigned feat_bytes,
           greg[par][m] = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)src * ROWB + c * 16, 0, 0);
         }
       }
-      // (2) this phase: the row blocks that have a partner under this offset
+      // (2) this phase: the row blocks that have a partner under this offset.  In mask order
+      //     nearly every phase has all of the wave's blocks active: that case is a straight line
+      //     (a branch per block and MFMA measured a wait in front of every MFMA); the rest takes
+      //     the blocks one by one.
       if (kk >= 0 && kk < nact) {
-        const int bm = __builtin_amdgcn_readfirstlane(s_list[kk]) >> 8;
+        const int bmw =
+            (__builtin_amdgcn_readfirstlane(s_list[kk]) >> (8 + rg * MBW)) & ((1 << MBW) - 1);
         const char *sa = reinterpret_cast<const char *>(s_a[par]);
-        auto a_read = [&](f32x4(&a)[MBW], int t) {
-#pragma unroll
-          for (int mb = 0; mb < MBW; ++mb) {
-            if (!((bm >> (rg * MBW + mb)) & 1)) continue;  // uniform
-            const int p = (rg * MBW + mb) * 16 + ln;
-            a[mb] = *reinterpret_cast<const f32x4 *>(sa + p * ROWB +
-                                                     16 * ATileF<CIN>::pos(p, 4 * t + g));
-          }
+        auto a_at = [&](int mb, int t) {
+          const int p = (rg * MBW + mb) * 16 + ln;
+          return *reinterpret_cast<const f32x4 *>(sa + p * ROWB + 16 * ATileF<CIN>::pos(p, 4 * t + g));
         };
-        f32x4 a[2][MBW];
-        a_read(a[0], 0);
+        if (bmw == (1 << MBW) - 1) {
+          f32x4 a[2][MBW];
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-          if (t + 1 < T) a_read(a[(t + 1) & 1], t + 1);
-          __builtin_amdgcn_sched_barrier(0);
+          for (int mb = 0; mb < MBW; ++mb) a[0][mb] = a_at(mb, 0);
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
+          for (int t = 0; t < T; ++t) {
+            if (t + 1 < T) {
 #pragma unroll
-            for (int mb = 0; mb < MBW; ++mb)
-              if ((bm >> (rg * MBW + mb)) & 1) {
+              for (int mb = 0; mb < MBW; ++mb) a[(t + 1) & 1][mb] = a_at(mb, t + 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int mb = 0; mb < MBW; ++mb)
 #pragma unroll
                 for (int i = 0; i < NBW; ++i)
                   acc[mb][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[par][i][t][j], a[t & 1][mb][j],
                                                                    acc[mb][i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else if (bmw != 0) {
+#pragma unroll
+          for (int mb = 0; mb < MBW; ++mb)
+            if ((bmw >> mb) & 1) {  // uniform
+#pragma unroll
+              for (int t = 0; t < T; ++t) {
+                const f32x4 av = a_at(mb, t);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                  for (int i = 0; i < NBW; ++i)
+                    acc[mb][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[par][i][t][j], av[j],
+                                                                     acc[mb][i], 0, 0, 0);
               }
-          __builtin_amdgcn_sched_barrier(0);
+            }
         }
       }
       // (3) park the rows of phase kk+1 (issued one phase ago) in the other LDS buffer
@@ -286,7 +304,7 @@ int dispatch_ordered(int cout, const OrdArgs &a) {
   switch (cout) {
     case 16: return launch_ordered<CIN, 16, 64, 1, 4, 2>(a);
     case 32: return launch_ordered<CIN, 32, 64, 2, 4, 2>(a);
-    case 64: return launch_ordered<CIN, 64, 64, 4, 4, 2>(a);
+    case 64: return launch_ordered<CIN, 64, 64, 4, 4, (CIN <= 64 ? 3 : 2)>(a);
     case 128:
       if constexpr (CIN >= 128) return launch_ordered<CIN, 128, 64, 8, 8, 1>(a);
       else return launch_ordered<CIN, 128, 64, 4, 4, 2>(a);
