@@ -136,7 +136,7 @@ sparse_conv_f32_kernel(const float *__restrict__ feat, const int *__restrict__ n
                        const float *__restrict__ scale, const float *__restrict__ shift,
                        const float *__restrict__ residual, int relu, float *__restrict__ out,
                        const int *n_out_dev, int n_out_bound, int balance,
-                       unsigned long long *__restrict__ prof) {
+                       unsigned long long *__restrict__ prof, const int *__restrict__ order) {
   constexpr int NT = WAVES * 64;
   constexpr int CINP = CIN < 16 ? 16 : CIN;  // packed-weight K extent
   constexpr int T = CINP / 16;               // 16-channel groups = float4 B fragments per N block
@@ -193,14 +193,18 @@ sparse_conv_f32_kernel(const float *__restrict__ feat, const int *__restrict__ n
     const int row_end = (row0 + tm < n_out) ? row0 + tm : n_out;
     // ---- setup: compact the tile's pairs per offset, clear the output tile --------------
     int nv[KPW][HALVES];
+    int orow[HALVES];  // output row of tile entry h*64+lane (identity without a row order)
+#pragma unroll
+    for (int h = 0; h < HALVES; ++h) {
+      const int o = row0 + h * 64 + lane;
+      orow[h] = o < row_end ? (order ? order[o] : o) : -1;
+    }
 #pragma unroll
     for (int i = 0; i < KPW; ++i) {
       const int k = wave + i * WAVES;
 #pragma unroll
-      for (int h = 0; h < HALVES; ++h) {
-        int o = row0 + h * 64 + lane;
-        nv[i][h] = (k < K && o < row_end) ? nbr[(size_t)k * nbr_stride + o] : -1;
-      }
+      for (int h = 0; h < HALVES; ++h)
+        nv[i][h] = (k < K && orow[h] >= 0) ? nbr[(size_t)k * nbr_stride + orow[h]] : -1;
     }
 #pragma unroll
     for (int i = 0; i < KPW; ++i) {
@@ -359,6 +363,7 @@ sparse_conv_f32_kernel(const float *__restrict__ feat, const int *__restrict__ n
     for (int idx = tid; idx < TM * OC; idx += NT) {
       int r = idx / OC, c = idx % OC, row = row0 + r;
       if (row >= row_end) continue;
+      if (order) row = order[row];
       f32x4 v = *reinterpret_cast<const f32x4 *>(&s_out[r * OST + 4 * c]);
       if (scale) {
         f32x4 sc = *reinterpret_cast<const f32x4 *>(scale + 4 * c);
@@ -584,7 +589,8 @@ sparse_conv_f32_wide_kernel(const float *__restrict__ feat, const int *__restric
                             const float *__restrict__ scale, const float *__restrict__ shift,
                             const float *__restrict__ residual, int relu, float *__restrict__ out,
                             const int *n_out_dev, int n_out_bound, int balance,
-                            unsigned long long *__restrict__ prof) {
+                            unsigned long long *__restrict__ prof,
+                            const int *__restrict__ order) {
   using S = WideShape<CIN, COUT, TM, AM, WAVES>;
   constexpr int NT = S::NT, T = S::T, NBW = S::NBW, OST = S::OST, TMP = S::TMP, GI = S::GI;
   constexpr int HALVES = S::HALVES, KPW = S::KPW, NMETA = S::NMETA;
@@ -624,14 +630,18 @@ sparse_conv_f32_wide_kernel(const float *__restrict__ feat, const int *__restric
     const int row_end = (row0 + tm < n_out) ? row0 + tm : n_out;
     // ---- setup: compact the tile's pairs per offset, clear the output tile --------------
     int nv[KPW][HALVES];
+    int orow[HALVES];  // output row of tile entry h*64+lane (identity without a row order)
+#pragma unroll
+    for (int h = 0; h < HALVES; ++h) {
+      const int o = row0 + h * 64 + lane;
+      orow[h] = o < row_end ? (order ? order[o] : o) : -1;
+    }
 #pragma unroll
     for (int i = 0; i < KPW; ++i) {
       const int k = wave + i * WAVES;
 #pragma unroll
-      for (int h = 0; h < HALVES; ++h) {
-        int o = row0 + h * 64 + lane;
-        nv[i][h] = (k < K && o < row_end) ? nbr[(size_t)k * nbr_stride + o] : -1;
-      }
+      for (int h = 0; h < HALVES; ++h)
+        nv[i][h] = (k < K && orow[h] >= 0) ? nbr[(size_t)k * nbr_stride + orow[h]] : -1;
     }
 #pragma unroll
     for (int i = 0; i < KPW; ++i) {
@@ -728,6 +738,7 @@ sparse_conv_f32_wide_kernel(const float *__restrict__ feat, const int *__restric
     for (int idx = tid; idx < TM * OC; idx += NT) {
       int r = idx / OC, c = idx % OC, row = row0 + r;
       if (row >= row_end) continue;
+      if (order) row = order[row];
       f32x4 v = *reinterpret_cast<const f32x4 *>(&s_out[r * OST + 4 * c]);
       if (scale) {
         f32x4 sc = *reinterpret_cast<const f32x4 *>(scale + 4 * c);
@@ -898,6 +909,7 @@ __global__ void pad_channels_kernel(const float *__restrict__ src, int cs, float
 }
 
 unsigned long long *g_conv_prof = nullptr;  // diagnostic only, see sf_debug_conv_profile
+const int *g_row_order = nullptr;            // experiment hook, see sf_debug_conv_row_order
 
 struct ConvArgs {
   const float *feat;
@@ -952,7 +964,7 @@ int launch(const ConvArgs &a, int balance_default) {
   hipLaunchKernelGGL((sparse_conv_f32_kernel<CIN, COUT, TM, AM, WAVES, ABUF>), dim3(grid),
                      dim3(WAVES * 64), 0, a.st, a.feat, a.nbr, a.nbr_stride, a.K, a.k_first, a.wpk,
                      a.scale, a.shift, a.residual, a.relu, a.out, a.n_out_dev, a.n_out_bound,
-                     balance, g_conv_prof);
+                     balance, g_conv_prof, g_row_order);
   SF_CHECK_LAUNCH();
   return SF_OK;
 }
@@ -989,7 +1001,7 @@ int launch_wide(const ConvArgs &a, int balance_default) {
     hipLaunchKernelGGL((sparse_conv_f32_wide_kernel<CIN, COUT, TM, AM, WAVES, MINW>), dim3(grid),
                        dim3(WAVES * 64), 0, a.st, a.feat, a.nbr, a.nbr_stride, a.K, a.k_first, a.wpk,
                        a.scale, a.shift, a.residual, a.relu, a.out, a.n_out_dev, a.n_out_bound,
-                       balance, g_conv_prof);
+                       balance, g_conv_prof, g_row_order);
     SF_CHECK_LAUNCH();
     return SF_OK;
   }
@@ -1203,4 +1215,8 @@ extern "C" int sf_sparse_conv_f32(const float *features_in, int cin_padded, cons
 // buffer of 16 uint64, every conv launch accumulates wave-0 cycle stamps per region into it.
 extern "C" __attribute__((visibility("default"))) void sf_debug_conv_profile(void *dev_buf16) {
   g_conv_prof = (unsigned long long *)dev_buf16;
+}
+// Experiment hook: a row order (sf_row_order_by_mask) for the tiles of the wide kernel; NULL = off.
+extern "C" __attribute__((visibility("default"))) void sf_debug_conv_row_order(const void *order) {
+  g_row_order = (const int *)order;
 }

@@ -24,6 +24,8 @@ def main():
     ap.add_argument('--batch', type=int, default=1)
     ap.add_argument('--reps', type=int, default=10)
     ap.add_argument('--natural', action='store_true', help='no row order (natural order)')
+    ap.add_argument('--wide-order', action='store_true',
+                    help='B side = the compacting wide kernel of sf_sparse_conv_f32 with the mask row order')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     pts = [synth.nuscenes_frame(args.frame + b) for b in range(args.batch)]
@@ -79,7 +81,20 @@ def main():
         t_a = timeit(lambda: _lib.check(real(feat, cinp, nbr, stride, K, kf, wpk, cout, scale, shift,
                                              res, relu, ref.data_ptr(), n_dev, n_bound, stream)))
         optr = None if args.natural else order.data_ptr()
-        t_b = timeit(lambda: _lib.check(L.sf_sparse_conv_f32_ordered(
+        if args.wide_order:
+            import ctypes
+            raw = ctypes.CDLL(_lib.LIB_PATH)
+            raw.sf_debug_conv_row_order.argtypes = [ctypes.c_void_p]
+
+            def run_b():
+                raw.sf_debug_conv_row_order(order.data_ptr())
+                rc_ = real(feat, cinp, nbr, stride, K, kf, wpk, cout, scale, shift, res, relu,
+                           alt.data_ptr(), n_dev, n_bound, stream)
+                raw.sf_debug_conv_row_order(None)
+                _lib.check(rc_)
+            t_b = timeit(run_b)
+        else:
+          t_b = timeit(lambda: _lib.check(L.sf_sparse_conv_f32_ordered(
             feat, n_in_bound, cinp, nbr, stride, K, kf, optr, wpk, cout, scale, shift, res, relu,
             alt.data_ptr(), n_dev, n_bound, stream)))
         a_, b_ = ref[:n_out], alt[:n_out]
