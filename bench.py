@@ -40,7 +40,8 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA dense peak (no 2:1 sparsity)
 
 
-def build_backbone(workload, dev, batch, max_points, overlap=True, dtype='f32', second=False):
+def build_backbone(workload, dev, batch, max_points, overlap=True, dtype='f32', second=False,
+                   strided_growth=None):
     cfg = configs.NUSC if workload == 'nusc' else configs.WAYMO
     ecfg = dict(cfg['pts_middle_encoder'])
     ecfg.pop('type')
@@ -72,7 +73,7 @@ def build_backbone(workload, dev, batch, max_points, overlap=True, dtype='f32', 
         bev_backbone, neck = bev_backbone.to(dev).eval(), neck.to(dev).eval()
     bb = LidarBackbone(cfg['pts_voxel_layer'], enc, dev, max_points, batch_size=batch,
                        overlap=overlap, dtype=dtype, voxel_encoder=vfe, bev_backbone=bev_backbone,
-                       neck=neck)
+                       neck=neck, strided_growth=strided_growth)
     return cfg, ecfg, sd, enc, bb
 
 
@@ -234,6 +235,9 @@ def main():
     ap.add_argument('--second', action='store_true',
                     help='also run SECOND + SECONDFPN on the BEV map inside the step (SURVEY 8f-3; '
                          'an extended workload, not the headline metric)')
+    ap.add_argument('--strided-growth', type=float, default=None,
+                    help='bound on output/input rows of a strided conv for sizing (default: the '
+                         'geometric worst case, 8); overflow is detected, never silent')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-overlap', action='store_true',
                     help='coordinate phase on the main stream instead of a forked one')
@@ -268,12 +272,13 @@ def main():
     host_frames = [gen(i) for i in ids]
     max_pts = max(p.shape[0] for p in host_frames)
     cfg, ecfg, sd, enc, bb = build_backbone(args.workload, dev, B, max_pts, not args.no_overlap,
-                                            args.dtype, args.second)
+                                            args.dtype, args.second, args.strided_growth)
     # frames in flight: independent frames on independent streams fill each other's tail rounds
     # and barrier bubbles; every stream has its own workspace, weights are shared
     lanes = [bb] + [LidarBackbone(cfg['pts_voxel_layer'], enc, dev, max_pts, batch_size=B,
                                   overlap=not args.no_overlap, dtype=args.dtype,
-                                  voxel_encoder=bb.vfe, bev_backbone=bb.bev_backbone, neck=bb.neck)
+                                  voxel_encoder=bb.vfe, bev_backbone=bb.bev_backbone, neck=bb.neck,
+                                  strided_growth=args.strided_growth)
                     for _ in range(args.streams - 1)]
     streams = [torch.cuda.Stream(device=dev) for _ in lanes]
     frames = [[torch.from_numpy(host_frames[f * B + b]).to(dev) for b in range(B)]

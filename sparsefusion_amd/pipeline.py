@@ -58,7 +58,7 @@ class LidarBackbone:
     def __init__(self, voxel_layer_cfg, encoder, device, max_points, batch_size=1,
                  materialize_voxels=True, training=False, overlap=True, dtype='f32',
                  voxel_encoder=None, bev_backbone=None, neck=None,
-                 heights_out_size_factor=None):
+                 heights_out_size_factor=None, strided_growth=None):
         """dtype 'f32': every layer on the exact-fp32 kernels.  'bf16' (BASELINE configs[2]): the
         first layer stays fp32 (raw metric coordinates need more than 8 significant bits), its
         output is cast to bf16, every later layer runs on the bf16 matrix cores with fp32
@@ -66,6 +66,12 @@ class LidarBackbone:
         assert isinstance(encoder, SparseEncoder)
         assert dtype in ('f32', 'bf16')
         self.dtype = dtype
+        # strided_growth: bound on (output rows / input rows) of a strided convolution used to size
+        # buffers and hash tables.  None = the geometric worst case (8 for 3x3x3 / stride 2: always
+        # safe).  LiDAR frames stay far below it (1.3, 0.6, 0.33 on the nuScenes-shaped frames); a
+        # smaller value shrinks the hash tables (fewer cache misses per probe, less to clear) and
+        # is guarded by the overflow flag: results() reports it and nothing is written out of bounds.
+        self.strided_growth = None if strided_growth is None else float(strided_growth)
         # bev_backbone / neck: optional SECOND / SECONDFPN modules (second.py) run on the dense map
         # in the same enqueue (detectors/sparsefusion.py:123-126); enqueue then returns what they
         # return (the neck's single map, or the backbone's tuple) instead of the BEV map
@@ -144,7 +150,10 @@ class LidarBackbone:
                     for k, s in zip(ks, st):
                         reach *= (k + s - 1) // s
                     vol = self.B * oshape[0] * oshape[1] * oshape[2]
-                    self.sets.append(dict(shape=oshape, bound=max(min(s_in['bound'] * reach, vol), 1)))
+                    if self.strided_growth is not None:
+                        reach = min(reach, self.strided_growth)
+                    self.sets.append(dict(shape=oshape,
+                                          bound=max(min(int(s_in['bound'] * reach), vol), 1)))
                     dst = len(self.sets) - 1
                 rb_index[key] = len(self.rulebooks)
                 self.rulebooks.append(dict(src=cur, dst=dst, ks=list(ks), st=list(st), pd=list(pd),
