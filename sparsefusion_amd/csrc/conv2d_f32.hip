@@ -50,7 +50,7 @@ struct Conv2dArgs {
   int nct, nxt, nyt, nchunks, n_wg;
 };
 
-template <int KS, int S, int TH>
+template <int KS, int S, int TH, int NG = 4>
 struct Geo {
   static constexpr int CK = stage_channels(KS);
   static constexpr int CKG = CK / 4;
@@ -58,24 +58,26 @@ struct Geo {
   static constexpr int PH = (TH - 1) * S + KS;
   static constexpr int PW = (TW - 1) * S + KS;
   static constexpr int CS = (S == 1) ? ((PH * PW + 15) / 32 * 32 + 16) : ((PH * PW) | 1);
-  static constexpr int W4 = TAPS * CKG * 64;  // float4 per filter stage
-  static constexpr int W_FLOATS = W4 * 4;
+  static constexpr int W4 = TAPS * CKG * 64;  // float4 per filter stage of a 64-channel tile
+  static constexpr int WV = W4;                // per-lane filter pieces of this workgroup's stage
+  static constexpr int W_FLOATS = WV * NG;     // (NG floats each)
   static constexpr int P_ELEMS = CK * PH * PW;
   static constexpr int DUMMY = CK * CS;          // patch slot that absorbs out-of-range fill lanes
   static constexpr int STAGE = W_FLOATS + CK * CS + 4;
   static constexpr int THREADS = TH * 64;
-  static constexpr int NW4 = (W4 + THREADS - 1) / THREADS;
+  static constexpr int NW4 = (WV + THREADS - 1) / THREADS;
   static constexpr int NP = (P_ELEMS + THREADS - 1) / THREADS;
   static constexpr size_t LDS_BYTES = 2u * STAGE * sizeof(float);
   static_assert(NP <= 32, "okmask holds one bit per patch element of a thread");
 };
 
-template <int KS, int S, int TH>
+template <int KS, int S, int TH, int NG>
 __global__ void __launch_bounds__(TH * 64)
 conv2d_f32_kernel(const float *__restrict__ in, const f32x4 *__restrict__ wp,
                   const float *__restrict__ scale, const float *__restrict__ shift,
                   float *__restrict__ out, const Conv2dArgs a) {
-  using G = Geo<KS, S, TH>;
+  using G = Geo<KS, S, TH, NG>;
+  typedef float wvec __attribute__((ext_vector_type(NG)));  // a lane's filter piece
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wr = tid >> 6;
 
@@ -85,8 +87,11 @@ conv2d_f32_kernel(const float *__restrict__ in, const f32x4 *__restrict__ wp,
   const int per = (a.n_wg + 7) >> 3;
   int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   if (t >= a.n_wg) return;
-  const int ct = t % a.nct;
+  // channel tile: nct tiles of 16*NG channels; the packed filters are laid out per 64 channels,
+  // a 32-channel workgroup reads one half of every lane's float4
+  const int ctn = t % a.nct;
   t /= a.nct;
+  const int ct = ctn * NG / 4, half = (NG == 4) ? 0 : (ctn & 1);
   const int xt = t % a.nxt;
   t /= a.nxt;
   const int yt = t % a.nyt, b = t / a.nyt;
@@ -110,7 +115,7 @@ conv2d_f32_kernel(const float *__restrict__ in, const f32x4 *__restrict__ wp,
     loff[i] = e < G::P_ELEMS ? c * G::CS + rem : G::DUMMY;
   }
 
-  f32x4 wreg[G::NW4];
+  wvec wreg[G::NW4];
   float preg[G::NP];
   unsigned okmask = 0;  // bit i: preg[i] is a real input element (else the slot is zero padding)
 
@@ -121,8 +126,9 @@ conv2d_f32_kernel(const float *__restrict__ in, const f32x4 *__restrict__ wp,
 #pragma unroll
     for (int i = 0; i < G::NW4; ++i) {
       int idx = tid + i * G::THREADS;
-      if (G::W4 % G::THREADS != 0) idx = idx < G::W4 ? idx : G::W4 - 1;
-      wreg[i] = wct[(size_t)ch * G::W4 + idx];
+      if (G::WV % G::THREADS != 0) idx = idx < G::WV ? idx : G::WV - 1;
+      wreg[i] = *reinterpret_cast<const wvec *>(
+          reinterpret_cast<const float *>(wct + (size_t)ch * G::W4 + idx) + half * NG);
     }
     const int c0 = ch * G::CK, cbase = c0 * (int)plane;
     okmask = 0;
@@ -139,16 +145,16 @@ conv2d_f32_kernel(const float *__restrict__ in, const f32x4 *__restrict__ wp,
 #pragma unroll
     for (int i = 0; i < G::NW4; ++i) {
       const int idx = tid + i * G::THREADS;
-      if (G::W4 % G::THREADS == 0 || idx < G::W4) reinterpret_cast<f32x4 *>(st)[idx] = wreg[i];
+      if (G::WV % G::THREADS == 0 || idx < G::WV) reinterpret_cast<wvec *>(st)[idx] = wreg[i];
     }
 #pragma unroll
     for (int i = 0; i < G::NP; ++i)
       st[G::W_FLOATS + loff[i]] = (okmask >> i) & 1u ? preg[i] : 0.0f;
   };
 
-  f32x4 acc[4][2];
+  f32x4 acc[NG][2];
 #pragma unroll
-  for (int g = 0; g < 4; ++g)
+  for (int g = 0; g < NG; ++g)
 #pragma unroll
     for (int p = 0; p < 2; ++p) acc[g][p] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -163,7 +169,7 @@ conv2d_f32_kernel(const float *__restrict__ in, const f32x4 *__restrict__ wp,
     if (more) load_stage(ch + 1);
     if (row_live) {
       const float *st = lds + (ch & 1) * G::STAGE;
-      const f32x4 *wl = reinterpret_cast<const f32x4 *>(st) + lane;
+      const wvec *wl = reinterpret_cast<const wvec *>(st) + lane;
       const float *pl = st + G::W_FLOATS + pb;
 #pragma unroll
       for (int ky = 0; ky < KS; ++ky)
@@ -171,11 +177,11 @@ conv2d_f32_kernel(const float *__restrict__ in, const f32x4 *__restrict__ wp,
         for (int kx = 0; kx < KS; ++kx)
 #pragma unroll
           for (int cg = 0; cg < G::CKG; ++cg) {
-            const f32x4 wa = wl[((ky * KS + kx) * G::CKG + cg) * 64];
+            const wvec wa = wl[((ky * KS + kx) * G::CKG + cg) * 64];
             const float b0 = pl[cg * 4 * G::CS + ky * G::PW + kx];
             const float b1 = pl[cg * 4 * G::CS + ky * G::PW + kx + 16 * S];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
+            for (int g = 0; g < NG; ++g) {
               acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[g], b0, acc[g][0], 0, 0, 0);
               acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[g], b1, acc[g][1], 0, 0, 0);
             }
@@ -192,8 +198,8 @@ conv2d_f32_kernel(const float *__restrict__ in, const f32x4 *__restrict__ wp,
   const int oy = oy0 + wr;
   const int up = a.up, HO = a.Ho * up, WO = a.Wo * up;
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int cp0 = ct * TN + g * 16 + 4 * (lane >> 4);
+  for (int g = 0; g < NG; ++g) {
+    const int cp0 = ctn * 16 * NG + g * 16 + 4 * (lane >> 4);
     if (up == 1) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -297,11 +303,11 @@ __global__ void conv2d_pack_kernel(const float *__restrict__ w, int coutp, int c
   }
 }
 
-template <int KS, int S, int TH>
+template <int KS, int S, int TH, int NG>
 int launch(const float *in, const float *wp, const float *scale, const float *shift, float *out,
            Conv2dArgs a, hipStream_t st) {
-  using G = Geo<KS, S, TH>;
-  auto kern = conv2d_f32_kernel<KS, S, TH>;
+  using G = Geo<KS, S, TH, NG>;
+  auto kern = conv2d_f32_kernel<KS, S, TH, NG>;
   static bool attr_set = false;  // per instantiation; the attribute is sticky per function
   if (G::LDS_BYTES > 48 * 1024 && !attr_set) {
     SF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -309,6 +315,7 @@ int launch(const float *in, const float *wp, const float *scale, const float *sh
     attr_set = true;
   }
   a.nyt = sf_div_up(a.Ho, TH);
+  a.nct = sf_div_up(a.cout_packed, 16 * NG);
   a.n_wg = a.B * a.nyt * a.nxt * a.nct;
   const int grid = ((a.n_wg + 7) / 8) * 8;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(G::THREADS), G::LDS_BYTES, st, in,
@@ -318,14 +325,32 @@ int launch(const float *in, const float *wp, const float *scale, const float *sh
 }
 
 template <int KS, int S>
-int dispatch_th(int th, const float *in, const float *wp, const float *scale, const float *shift,
-                float *out, const Conv2dArgs &a, hipStream_t st) {
-  switch (th) {
-    case 2: return launch<KS, S, 2>(in, wp, scale, shift, out, a, st);
-    case 3: return launch<KS, S, 3>(in, wp, scale, shift, out, a, st);
-    case 4: return launch<KS, S, 4>(in, wp, scale, shift, out, a, st);
-    default: return launch<KS, S, 6>(in, wp, scale, shift, out, a, st);
+int dispatch_th(int th, int ng, const float *in, const float *wp, const float *scale,
+                const float *shift, float *out, const Conv2dArgs &a, hipStream_t st) {
+  if (ng == 2) {
+    if (th == 6) return launch<KS, S, 6, 2>(in, wp, scale, shift, out, a, st);
+    return launch<KS, S, 4, 2>(in, wp, scale, shift, out, a, st);
   }
+  switch (th) {
+    case 2: return launch<KS, S, 2, 4>(in, wp, scale, shift, out, a, st);
+    case 3: return launch<KS, S, 3, 4>(in, wp, scale, shift, out, a, st);
+    case 4: return launch<KS, S, 4, 4>(in, wp, scale, shift, out, a, st);
+    default: return launch<KS, S, 6, 4>(in, wp, scale, shift, out, a, st);
+  }
+}
+
+// Channels per workgroup: 64, or 32 where the 64-channel grid is about two workgroups per CU (one
+// 180x180 map at batch 1: 540 workgroups on 256 CUs; 1080 half-width ones measured 4 % faster:
+// 131 vs 137 us for 128->128).  Smaller grids (a 90x90 map: 276) and the 1x1 / stride-2 layers
+// measured SLOWER with 32 channels (169 vs 161 us, 92 vs 80 us): they keep 64.  SF_CONV2D_NG=2|4
+// overrides.
+int pick_groups(const Conv2dArgs &a, int th) {
+  if (const char *e = getenv("SF_CONV2D_NG")) {
+    const int v = atoi(e);
+    if (v == 2 || v == 4) return v;
+  }
+  const long long wgs = (long long)a.B * sf_div_up(a.Ho, th) * a.nxt * sf_div_up(a.cout_packed, 64);
+  return (wgs >= 400 && wgs < 4 * 256 && a.cout_packed % 32 == 0) ? 2 : 4;
 }
 
 // Rows (= waves) per workgroup.  4 puts one wave of every workgroup on each SIMD and measured
@@ -393,11 +418,11 @@ extern "C" int sf_conv2d_f32(const float *in, const float *packed, const float *
   SF_CHECK_ARG((long long)cin * h * w < (1ll << 31), "one sample of the input must stay below 2^31 elements");
   SF_CHECK_ARG((long long)batch * sf_div_up(ho, 2) * a.nxt * a.nct < (1ll << 30), "grid too large");
   hipStream_t st = (hipStream_t)stream;
-  const int th = pick_rows(a);
-  if (ksize == 3 && stride == 1) return dispatch_th<3, 1>(th, in, packed, scale, shift, out, a, st);
-  if (ksize == 3 && stride == 2) return dispatch_th<3, 2>(th, in, packed, scale, shift, out, a, st);
-  if (ksize == 1 && stride == 1) return dispatch_th<1, 1>(th, in, packed, scale, shift, out, a, st);
-  if (ksize == 2 && stride == 2) return dispatch_th<2, 2>(th, in, packed, scale, shift, out, a, st);
+  const int th = pick_rows(a), ng = pick_groups(a, th);
+  if (ksize == 3 && stride == 1) return dispatch_th<3, 1>(th, ng, in, packed, scale, shift, out, a, st);
+  if (ksize == 3 && stride == 2) return dispatch_th<3, 2>(th, ng, in, packed, scale, shift, out, a, st);
+  if (ksize == 1 && stride == 1) return dispatch_th<1, 1>(th, ng, in, packed, scale, shift, out, a, st);
+  if (ksize == 2 && stride == 2) return dispatch_th<2, 2>(th, ng, in, packed, scale, shift, out, a, st);
   sf_set_error("conv2d kernel %d / stride %d not supported (3/1, 3/2, 1/1, 2/2)", ksize, stride);
   return SF_ERR_BAD_ARG;
 }
