@@ -75,3 +75,29 @@ def test_conv_output_size_rule():
     assert spconv.get_conv_output_size([41, 1440, 1440], [3] * 3, [2] * 3, [1] * 3, [1] * 3) == [21, 720, 720]
     assert spconv.get_conv_output_size([11, 360, 360], [3] * 3, [2] * 3, [0, 1, 1], [1] * 3) == [5, 180, 180]
     assert spconv.get_conv_output_size([5, 180, 180], [3, 1, 1], [2, 1, 1], [0] * 3, [1] * 3) == [2, 180, 180]
+
+
+def test_ordered_kernel_selection(monkeypatch):
+    """SF_CONV_ORDERED: which fp32 layer shapes run on the mask-ordered kernel (default: none)."""
+    monkeypatch.delenv('SF_CONV_ORDERED', raising=False)
+    assert not spconv.use_ordered(64, 64)
+    monkeypatch.setenv('SF_CONV_ORDERED', '32x32,64x64')
+    assert spconv.use_ordered(64, 64) and spconv.use_ordered(32, 32)
+    assert not spconv.use_ordered(128, 128) and not spconv.use_ordered(8, 16)
+    monkeypatch.setenv('SF_CONV_ORDERED', 'all')
+    assert spconv.use_ordered(128, 64) and not spconv.use_ordered(8, 16)   # first layer: cin < 16
+    monkeypatch.setenv('SF_CONV_ORDERED', 'none')
+    assert not spconv.use_ordered(64, 64)
+
+
+def test_registry_builders_resolve_every_mirrored_module():
+    for kind, types in (('middle', ['SparseEncoder', 'SparseUNet', 'PointPillarsScatter']),
+                        ('voxel', ['HardSimpleVFE', 'HardVFE', 'PillarFeatureNet'])):
+        reg = registry.MIDDLE_ENCODERS if kind == 'middle' else registry.VOXEL_ENCODERS
+        registry._populate()
+        for t in types:
+            assert reg.get(t) is not None, t
+    assert registry.build_backbone(dict(type='SECOND', in_channels=8, out_channels=[8],
+                                        layer_nums=[1], layer_strides=[1])) is not None
+    assert registry.build_neck(dict(type='SECONDFPN', in_channels=[8], out_channels=[8],
+                                    upsample_strides=[1])) is not None
