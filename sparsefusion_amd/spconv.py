@@ -84,6 +84,22 @@ class Rulebook:
     def k_first(self):
         return (self.K - 1) // 2 if self.subm else -1
 
+    def row_order(self):
+        """Output rows sorted by neighbour mask (sf_row_order_by_mask), built once per rulebook:
+        the tile schedule of sf_sparse_conv_f32_ordered."""
+        if getattr(self, '_order', None) is None:
+            L = _lib.lib()
+            n = max(self.out_coords.n, 1)
+            dev = self.nbr.device
+            order = torch.empty(n, dtype=torch.int32, device=dev)
+            wsb = L.sf_row_order_workspace(n)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            _lib.check(L.sf_row_order_by_mask(self.nbr.data_ptr(), self.nbr.shape[1], self.K, None,
+                                              self.out_coords.n, order.data_ptr(), ws.data_ptr(), wsb,
+                                              _lib.stream(dev)))
+            self._order = order
+        return self._order
+
     def inverted(self):
         """Rulebook of the coupled inverse convolution (SparseInverseConv3d, conv.py:147-152 /
         spconv_ops.h:319-348 with inverse = 1): every pair (in, out) of offset k becomes (out, in)
@@ -407,6 +423,13 @@ def sparse_conv(features, packed_filters, cin, cout, rulebook, scale=None, shift
         if residual.shape != out.shape:
             raise RuntimeError('residual shape mismatch')
         residual = residual.contiguous()
+    if use_ordered(cp, cout) and n_out > 0:   # same selection as LidarBackbone: identical results
+        _lib.check(L.sf_sparse_conv_f32_ordered(
+            _lib.ptr(x), x.shape[0], cp, rulebook.nbr.data_ptr(), rulebook.nbr.shape[1], rulebook.K,
+            rulebook.k_first, rulebook.row_order().data_ptr(), _lib.ptr(packed_filters), cout,
+            _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(residual), 1 if relu else 0, out.data_ptr(),
+            None, n_out, _lib.stream(features.device)))
+        return out
     _lib.check(L.sf_sparse_conv_f32(
         _lib.ptr(x), cp, rulebook.nbr.data_ptr(), rulebook.nbr.shape[1], rulebook.K,
         rulebook.k_first, _lib.ptr(packed_filters), cout, _lib.ptr(scale), _lib.ptr(shift),
