@@ -7,10 +7,23 @@ voxelize_*.npz   inputs + outputs of the REFERENCE's own CPU voxelizer (oracle/_
                  mmdet3d/ops/voxel/src by oracle/build_ref.py).  voxelize_kitti_like uses the first
                  4096 points of the reference's demo/kitti_000008.bin (a data file, not source)
                  with caps that both trigger.
-encoder_*.npz    a small synthetic frame through the CPU ORACLE's SparseEncoder wiring (SURVEY G3/G4:
-                 rulebook counts per layer, per-layer feature statistics, the dense BEV).  The
-                 reference's spconv cannot be built here, so these pin the oracle against
-                 regressions and the GPU path against the oracle; they are not reference outputs.
+encoder_*.npz    a small synthetic frame through the SparseEncoder wiring (rulebook
+                 counts and sha256 per layer, per-layer feature statistics, the dense BEV) with the
+                 REFERENCE's own spconv-1.x CPU code doing the work: every rulebook comes from the
+                 compiled getIndicePairsSubM / getIndicePairsConv (include/spconv/geometry.h) and
+                 every convolution from the compiled gather / scatter-add functors
+                 (src/reordering.cc) + torch::mm_out, through oracle/_ref/spconv (built by
+                 oracle/build_ref.py).  Only the layer wiring, eval-mode BatchNorm and the dense
+                 scatter are the oracle's (oracle.sparse_encoder_forward with the two functions
+                 swapped).  The oracle must reproduce them: rulebooks bit for bit, features to
+                 1e-5 (GEMM summation order).
+fullsize_rulebooks.json
+                 SURVEY G5/G6: sha256 of the CPU-reference-ordered rulebooks (indiceNum, outids,
+                 used pair prefixes), row / pair counts for all 8 encoder rulebooks of the
+                 full-size frames the BASELINE configs name (nuScenes frame 0 at 41x1440x1440,
+                 B = 8 nuScenes frames 0-7, Waymo-shaped frame 0 at 41x1504x1504 with the
+                 150 000-voxel cap hit), computed BY THE COMPILED REFERENCE, plus the oracle's
+                 per-layer feature abs-mean for nuScenes frame 0.
 """
 import hashlib
 import os
@@ -24,7 +37,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(HERE))
 
 from oracle import build_ref, oracle as O  # noqa: E402
-from sparsefusion_amd import synth  # noqa: E402
+from sparsefusion_amd import configs, synth  # noqa: E402
 from helpers import SMALL_RANGE, SMALL_SHAPE, SMALL_VOXEL, small_points  # noqa: E402
 
 
@@ -38,9 +51,108 @@ def ref_voxelize(mod, pts, vs, rng, mp, mv):
     return vox[:k].numpy(), co[:k].numpy(), npv[:k].numpy()
 
 
+class reference_spconv:
+    """Context manager: oracle.get_indice_pairs / oracle.indice_conv -> the compiled reference."""
+
+    def __init__(self, ref):
+        self.ref = ref
+
+    def __enter__(self):
+        import torch
+        ref = self.ref
+        self.saved = (O.get_indice_pairs, O.indice_conv)
+
+        def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padding=0,
+                             dilation=1, subm=False):
+            ks, st, pd, dl = (O._triple(v) for v in (ksize, stride, padding, dilation))
+            oshape = list(spatial_shape) if subm else O.conv_output_size(spatial_shape, ks, st, pd, dl)
+            o, p, n = ref.get_indice_pairs(torch.from_numpy(np.ascontiguousarray(indices, np.int32)),
+                                           int(batch_size), oshape, ks, st, pd, dl, bool(subm))
+            return o.numpy().copy(), p.numpy(), n.numpy(), oshape
+
+        def indice_conv(features, filters_kio, pairs, num, n_out, subm):
+            t = lambda a, d: torch.from_numpy(np.ascontiguousarray(a, d))
+            return ref.indice_conv(t(features, np.float32), t(filters_kio, np.float32),
+                                   t(pairs, np.int32), t(num, np.int32), int(n_out), False,
+                                   bool(subm)).numpy()
+
+        O.get_indice_pairs, O.indice_conv = get_indice_pairs, indice_conv
+        return self
+
+    def __exit__(self, *exc):
+        O.get_indice_pairs, O.indice_conv = self.saved
+
+
+ENCODER_CHAIN = [(3, 1, 1, True), (3, 2, 1, False), (3, 1, 1, True), (3, 2, 1, False),
+                 (3, 1, 1, True), (3, 2, (0, 1, 1), False), (3, 1, 1, True),
+                 ((3, 1, 1), (2, 1, 1), 0, False)]
+
+
+def rulebook_digest(outids, pairs, num):
+    h = hashlib.sha256()
+    h.update(np.ascontiguousarray(num, np.int32).tobytes())
+    h.update(np.ascontiguousarray(outids, np.int32).tobytes())
+    for k in range(pairs.shape[0]):
+        h.update(np.ascontiguousarray(pairs[k, :, :int(num[k])], np.int32).tobytes())
+    return h.hexdigest()
+
+
+def fullsize(ref):
+    """G5/G6: digests of the full-size rulebooks, from the compiled reference."""
+    out = {}
+    nus, way = configs.NUSC, configs.WAYMO
+
+    def chain(idx, batch, shape):
+        rows = []
+        with reference_spconv(ref):
+            for ks, st, pd, subm in ENCODER_CHAIN:
+                o, p, n, oshape = O.get_indice_pairs(idx, batch, shape, ks, st, pd, 1, subm)
+                rows.append(dict(n_in=int(idx.shape[0]), n_out=int(o.shape[0]), pairs=int(n.sum()),
+                                 sha256=rulebook_digest(o, p, n)))
+                idx, shape = o, oshape
+        return rows
+
+    def voxels(cfg, pts):
+        vl = cfg['pts_voxel_layer']
+        mv = vl['max_voxels']
+        mv = mv[1] if isinstance(mv, (tuple, list)) else mv
+        return O.hard_voxelize(pts, vl['voxel_size'], vl['point_cloud_range'],
+                               vl['max_num_points'], mv)
+
+    shape = list(nus['pts_middle_encoder']['sparse_shape'])
+    v, c, n = voxels(nus, synth.nuscenes_frame(0))
+    out['nusc_frame0'] = chain(O.batch_coors([c]), 1, shape)
+    # per-layer feature statistics of the ORACLE on that frame (regression pin, not reference data)
+    enc = {k: nus['pts_middle_encoder'][k] for k in ('output_channels', 'encoder_channels',
+                                                     'encoder_paddings', 'block_type')}
+    sd = synth.encoder_state_dict(1, 5, **{k: enc[k] for k in ('output_channels', 'encoder_channels',
+                                                               'block_type')})
+    trace = {}
+    bev = O.sparse_encoder_forward(sd, O.vfe_mean(v, n, 5), O.batch_coors([c]), 1, shape, 5,
+                                   trace=trace, **enc)
+    out['nusc_frame0_features'] = dict(
+        weight_seed=1, layers=[dict(name=k, abs_mean=float(np.abs(t['features']).mean()),
+                                    abs_max=float(np.abs(t['features']).max()))
+                               for k, t in trace.items() if isinstance(t, dict)],
+        bev_abs_mean=float(np.abs(bev).mean()), bev_nonzero=int(np.count_nonzero(bev)))
+    coors = [voxels(nus, synth.nuscenes_frame(i))[1] for i in range(8)]
+    out['nusc_b8'] = chain(O.batch_coors(coors), 8, shape)
+    v, c, n = voxels(way, synth.waymo_frame(0))
+    out['waymo_frame0'] = chain(O.batch_coors([c]),
+                                1, list(way['pts_middle_encoder']['sparse_shape']))
+    out['waymo_frame0_voxels'] = int(c.shape[0])
+    import json
+    with open(os.path.join(HERE, 'fullsize_rulebooks.json'), 'w') as f:
+        json.dump(out, f, indent=1)
+    print('fullsize_rulebooks.json', {k: (len(v_) if isinstance(v_, list) else v_)
+                                      for k, v_ in out.items() if k != 'nusc_frame0_features'})
+
+
 def main():
     mod = build_ref.load_prebuilt() or build_ref.build()
     assert mod is not None, 'needs /root/reference'
+    ref = build_ref.load_prebuilt_spconv() or build_ref.build_spconv()
+    assert ref is not None, 'needs /root/reference and triton\'s cuda_runtime_api.h'
     kitti = np.fromfile('/root/reference/demo/kitti_000008.bin', dtype=np.float32).reshape(-1, 4)[:4096]
     pts = np.concatenate([kitti, np.zeros((kitti.shape[0], 1), np.float32)], 1)
     vs, rng = [0.075, 0.075, 0.2], [-54.0, -54.0, -5.0, 54.0, 54.0, 3.0]
@@ -70,7 +182,9 @@ def main():
         sd = synth.encoder_state_dict(77, 5, encoder_channels=cfg['encoder_channels'],
                                       block_type='basicblock')
         trace = {}
-        bev = O.sparse_encoder_forward(sd, feats, coors4, batch, SMALL_SHAPE, 5, trace=trace, **cfg)
+        with reference_spconv(ref):
+            bev = O.sparse_encoder_forward(sd, feats, coors4, batch, SMALL_SHAPE, 5, trace=trace,
+                                           **cfg)
         layers = [k for k in trace if isinstance(trace[k], dict)]
         out = dict(points_seed=np.int64([500 + b for b in range(batch)]),
                    points_n=np.int64([3000 - 1200 * b for b in range(batch)]),
@@ -87,6 +201,7 @@ def main():
                    layer_pairs_sha=np.array([hashlib.sha256(np.ascontiguousarray(
                        trace[k]['pairs']).tobytes()).hexdigest() for k in layers]))
         np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    fullsize(ref)
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -1,7 +1,9 @@
 """Committed golden vectors for the SparseEncoder path (tests/golden/encoder_b{1,2}.npz, made by
-tests/golden/make_golden.py from the CPU oracle): the oracle must keep reproducing them (CPU), and
-the HIP path must match them (GPU): rulebook counts and coordinates bit for bit, BEV within
-tolerance.  B=2 has unequal sample sizes (batch-index handling, detectors/sparsefusion.py:153-157)."""
+tests/golden/make_golden.py with the REFERENCE's compiled spconv-1.x CPU code -- oracle/_ref/spconv:
+geometry.h rulebooks, reordering.cc gather / scatter-add + torch::mm_out -- inside the oracle's
+layer wiring): the oracle must reproduce them (CPU: rulebooks bit for bit, BEV to 1e-5, the GEMM
+summation order being the only difference), and the HIP path must match them (GPU): rulebook
+counts and coordinates bit for bit, BEV within 1e-4.  B=2 has unequal sample sizes (batch-index handling, detectors/sparsefusion.py:153-157)."""
 import hashlib
 import os
 
@@ -37,7 +39,8 @@ def test_oracle_reproduces_golden(oracle, name, batch):
     trace = {}
     got = oracle.sparse_encoder_forward(sd, g['voxel_features'], g['coors'], batch, SMALL_SHAPE, 5,
                                         trace=trace, **CFG)
-    assert np.array_equal(got, bev)
+    assert np.array_equal(got != 0, bev != 0)
+    assert_close(got, bev, rtol=1e-5, atol_scale=1e-6)
     for i, k in enumerate(g['layer_names']):
         t = trace[str(k)]
         assert t['outids'].shape[0] == g['layer_rows'][i]

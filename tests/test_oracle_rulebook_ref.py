@@ -1,0 +1,175 @@
+"""CPU oracle pinning, rulebook + convolution part (runs without a GPU).
+
+oracle/sf_oracle.c's restatement of spconv 1.x (sfo_indice_pairs_subm / _conv, sfo_indice_conv) is
+held against the REFERENCE's own code compiled from its sources where they lie
+(oracle/_ref/spconv/spconv_ref.so, built by oracle/build_ref.py: getIndicePairsSubM /
+getIndicePairsConv / getValidOutPos of include/spconv/geometry.h:24-85,144-194,247-297 and the
+CPU gather / scatter-add functors of src/reordering.cc:20-50):
+
+* outids, indicePairs (K,2,N) and indiceNum compared with `==` -- the CPU reference's own ORDER
+  (outputs in first-touch order, pairs in input order), not only the canonical form;
+* every geometry the GPU rulebook tests use (tests/test_gpu_rulebook.py CASES), B in {1, 3}, the
+  chain through all 8 encoder rulebooks, edge inputs, and one full-size nuScenes-shaped frame;
+* features of one conv through the reference functors + torch::mm_out (the arithmetic of
+  spconv_ops.h:294-356) vs sfo_indice_conv at 1e-5 (same products, summation order of the
+  Cin-long dot products differs between torch's GEMM and the oracle's loop).
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import SMALL_RANGE, SMALL_SHAPE, SMALL_VOXEL, assert_close, small_points
+from sparsefusion_amd import configs, synth
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+
+CASES = [
+    (3, 1, 1, True),
+    (3, 2, 1, False),
+    (3, 2, (0, 1, 1), False),
+    ((3, 1, 1), (2, 1, 1), 0, False),
+    (3, 1, 0, False),
+    ((1, 3, 3), 1, 0, True),
+]
+ENCODER_CHAIN = [(3, 1, 1, True), (3, 2, 1, False), (3, 1, 1, True), (3, 2, 1, False),
+                 (3, 1, 1, True), (3, 2, (0, 1, 1), False), (3, 1, 1, True),
+                 ((3, 1, 1), (2, 1, 1), 0, False)]
+
+
+@pytest.fixture(scope='module')
+def ref():
+    from oracle import build_ref
+    mod = build_ref.load_prebuilt_spconv()
+    if mod is None:
+        pytest.skip('oracle/_ref/spconv not built (reference sources absent)')
+    return mod
+
+
+def _t3(v):
+    return [int(x) for x in v] if isinstance(v, (list, tuple)) else [int(v)] * 3
+
+
+def ref_pairs(ref, oracle, idx, batch, shape, ks, st, pd, subm):
+    ks, st, pd = _t3(ks), _t3(st), _t3(pd)
+    out_shape = list(shape) if subm else oracle.conv_output_size(shape, ks, st, pd, [1, 1, 1])
+    o, p, n = ref.get_indice_pairs(torch.from_numpy(np.ascontiguousarray(idx, np.int32)), batch,
+                                   out_shape, ks, st, pd, [1, 1, 1], subm)
+    return o.numpy(), p.numpy(), n.numpy(), out_shape
+
+
+def active_set(oracle, seed, n, batch=1, max_voxels=20000):
+    coors = []
+    for b in range(batch):
+        pts = small_points(seed + 17 * b, n + 311 * b)
+        _, c, _ = oracle.hard_voxelize(pts, SMALL_VOXEL, SMALL_RANGE, 5, max_voxels)
+        coors.append(c)
+    return oracle.batch_coors(coors)
+
+
+def assert_same_rulebook(a, b):
+    assert a[3] == b[3]
+    assert np.array_equal(a[2], b[2]), 'indiceNum'
+    assert np.array_equal(a[0], b[0]), 'outids'
+    assert np.array_equal(a[1], b[1]), 'indicePairs'
+
+
+@pytest.mark.parametrize('ks,st,pd,subm', CASES)
+@pytest.mark.parametrize('batch', [1, 3])
+def test_oracle_rulebook_equals_compiled_reference(ref, oracle, ks, st, pd, subm, batch):
+    idx = active_set(oracle, 3, 2500, batch)
+    assert_same_rulebook(oracle.get_indice_pairs(idx, batch, SMALL_SHAPE, ks, st, pd, 1, subm),
+                         ref_pairs(ref, oracle, idx, batch, SMALL_SHAPE, ks, st, pd, subm))
+
+
+def test_survey_recorded_pairs(ref):
+    """SURVEY 8c [probe]: SubM k=1 pairs (12,819,131) -> (13,820,131); strided k=3 pairs
+    (13,820,131) -> (7,410,66) at the nuScenes geometry."""
+    idx = torch.tensor([[0, 12, 819, 131], [0, 13, 820, 131]], dtype=torch.int32)
+    o, p, n = ref.get_indice_pairs(idx, 1, [41, 1440, 1440], [3] * 3, [1] * 3, [1] * 3, [1] * 3, True)
+    assert n[1] == 1 and p[1, 0, 0] == 0 and p[1, 1, 0] == 1 and n[13] == 2
+    o, p, n = ref.get_indice_pairs(idx[1:], 1, [21, 720, 720], [3] * 3, [2] * 3, [1] * 3, [1] * 3,
+                                   False)
+    assert n[3] == 1 and o[p[3, 1, 0]].tolist() == [0, 7, 410, 66]
+
+
+def test_chain_through_all_encoder_rulebooks(ref, oracle):
+    idx = active_set(oracle, 11, 6000, 2)
+    shape = list(SMALL_SHAPE)
+    for ks, st, pd, subm in ENCODER_CHAIN:
+        a = oracle.get_indice_pairs(idx, 2, shape, ks, st, pd, 1, subm)
+        assert_same_rulebook(a, ref_pairs(ref, oracle, idx, 2, shape, ks, st, pd, subm))
+        idx, shape = a[0], a[3]
+    assert idx.shape[0] > 0
+
+
+def test_edge_inputs(ref, oracle):
+    one = np.asarray([[0, 0, 0, 0]], np.int32)
+    corner = np.asarray([[0, 40, 159, 159], [0, 40, 159, 158], [0, 39, 159, 159]], np.int32)
+    for idx in (one, corner):
+        for ks, st, pd, subm in CASES:
+            assert_same_rulebook(oracle.get_indice_pairs(idx, 1, SMALL_SHAPE, ks, st, pd, 1, subm),
+                                 ref_pairs(ref, oracle, idx, 1, SMALL_SHAPE, ks, st, pd, subm))
+
+
+def rulebook_digest(outids, pairs, num):
+    """sha256 over the CPU-reference-ordered rulebook: indiceNum, outids, and the used prefix of
+    every (in, out) pair row.  Shared with the full-size GPU parity tests."""
+    h = hashlib.sha256()
+    h.update(np.ascontiguousarray(num, np.int32).tobytes())
+    h.update(np.ascontiguousarray(outids, np.int32).tobytes())
+    for k in range(pairs.shape[0]):
+        h.update(np.ascontiguousarray(pairs[k, :, :int(num[k])], np.int32).tobytes())
+    return h.hexdigest()
+
+
+def test_full_size_frame_and_committed_digests(ref, oracle):
+    """nuScenes-shaped frame 0 at 41x1440x1440 through all 8 rulebooks: oracle == compiled
+    reference, and == the digests committed in tests/golden/fullsize_rulebooks.json (written by
+    tests/golden/make_golden.py FROM THE COMPILED REFERENCE), which the full-size GPU tests pin
+    the HIP rulebooks to."""
+    cfg = configs.NUSC['pts_voxel_layer']
+    pts = synth.nuscenes_frame(0)
+    _, c, _ = oracle.hard_voxelize(pts, cfg['voxel_size'], cfg['point_cloud_range'], 10, 160000)
+    idx = oracle.batch_coors([c])
+    shape = list(configs.NUSC['pts_middle_encoder']['sparse_shape'])
+    with open(os.path.join(GOLD, 'fullsize_rulebooks.json')) as f:
+        gold = json.load(f)['nusc_frame0']
+    for i, (ks, st, pd, subm) in enumerate(ENCODER_CHAIN):
+        a = oracle.get_indice_pairs(idx, 1, shape, ks, st, pd, 1, subm)
+        assert_same_rulebook(a, ref_pairs(ref, oracle, idx, 1, shape, ks, st, pd, subm))
+        assert rulebook_digest(a[0], a[1], a[2]) == gold[i]['sha256']
+        assert int(a[2].sum()) == gold[i]['pairs'] and a[0].shape[0] == gold[i]['n_out']
+        idx, shape = a[0], a[3]
+
+
+@pytest.mark.parametrize('ks,st,pd,subm,cin,cout', [(3, 1, 1, True, 16, 16), (3, 2, 1, False, 16, 32),
+                                                    ((3, 1, 1), (2, 1, 1), 0, False, 128, 128),
+                                                    (3, 1, 1, True, 5, 16)])
+def test_oracle_conv_equals_reference_functors(ref, oracle, ks, st, pd, subm, cin, cout):
+    idx = active_set(oracle, 5, 3000, 2)
+    outids, pairs, num, _ = oracle.get_indice_pairs(idx, 2, SMALL_SHAPE, ks, st, pd, 1, subm)
+    rng = np.random.default_rng(7)
+    feats = rng.standard_normal((idx.shape[0], cin)).astype(np.float32)
+    K = pairs.shape[0]
+    w = (rng.standard_normal((K, cin, cout)) / np.sqrt(K * cin)).astype(np.float32)
+    got = oracle.indice_conv(feats, w, pairs, num, outids.shape[0], subm)
+    exp = ref.indice_conv(torch.from_numpy(feats), torch.from_numpy(w), torch.from_numpy(pairs),
+                          torch.from_numpy(num), outids.shape[0], False, subm).numpy()
+    assert_close(got, exp, rtol=1e-5, atol_scale=1e-6)
+
+
+def test_oracle_inverse_conv_equals_reference_functors(ref, oracle):
+    """inverse = 1 (spconv_ops.h:319-348): gather through pair column 1, scatter through column 0."""
+    idx = active_set(oracle, 9, 2000, 1)
+    outids, pairs, num, _ = oracle.get_indice_pairs(idx, 1, SMALL_SHAPE, 3, 2, 1, 1, False)
+    rng = np.random.default_rng(3)
+    feats = rng.standard_normal((outids.shape[0], 32)).astype(np.float32)
+    w = (rng.standard_normal((27, 32, 16)) / 30).astype(np.float32)
+    got = oracle.indice_inverse_conv(feats, w, pairs, num, idx.shape[0])
+    exp = ref.indice_conv(torch.from_numpy(feats), torch.from_numpy(w), torch.from_numpy(pairs),
+                          torch.from_numpy(num), idx.shape[0], True, False).numpy()
+    assert_close(got, exp, rtol=1e-5, atol_scale=1e-6)
