@@ -1,4 +1,8 @@
 """Shared helpers for the parity tests (test infrastructure)."""
+import hashlib
+import json
+import os
+
 import numpy as np
 import torch
 
@@ -48,3 +52,28 @@ def rel_err(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+# the chain of rulebook geometries of the target SparseEncoder:
+# subm1, spconv1, subm2, spconv2, subm3, spconv3, subm4, spconv_down2
+ENCODER_CHAIN = [(3, 1, 1, True), (3, 2, 1, False), (3, 1, 1, True), (3, 2, 1, False),
+                 (3, 1, 1, True), (3, 2, (0, 1, 1), False), (3, 1, 1, True),
+                 ((3, 1, 1), (2, 1, 1), 0, False)]
+
+
+def rulebook_digest(outids, pairs, num):
+    """sha256 over a rulebook in the CPU reference's order: indiceNum, outids, and the used prefix
+    of every (in, out) pair row (the unused tail of indicePairs is -1 padding)."""
+    h = hashlib.sha256()
+    h.update(np.ascontiguousarray(num, np.int32).tobytes())
+    h.update(np.ascontiguousarray(outids, np.int32).tobytes())
+    for k in range(pairs.shape[0]):
+        h.update(np.ascontiguousarray(pairs[k, :, :int(num[k])], np.int32).tobytes())
+    return h.hexdigest()
+
+
+def fullsize_golden():
+    """tests/golden/fullsize_rulebooks.json: digests computed by the COMPILED REFERENCE
+    (tests/golden/make_golden.py)."""
+    with open(os.path.join(os.path.dirname(__file__), 'golden', 'fullsize_rulebooks.json')) as f:
+        return json.load(f)

@@ -14,18 +14,13 @@ CPU gather / scatter-add functors of src/reordering.cc:20-50):
   spconv_ops.h:294-356) vs sfo_indice_conv at 1e-5 (same products, summation order of the
   Cin-long dot products differs between torch's GEMM and the oracle's loop).
 """
-import hashlib
-import json
-import os
-
 import numpy as np
 import pytest
 import torch
 
-from helpers import SMALL_RANGE, SMALL_SHAPE, SMALL_VOXEL, assert_close, small_points
+from helpers import (ENCODER_CHAIN, SMALL_RANGE, SMALL_SHAPE, SMALL_VOXEL, assert_close,
+                     fullsize_golden, rulebook_digest, small_points)
 from sparsefusion_amd import configs, synth
-
-GOLD = os.path.join(os.path.dirname(__file__), 'golden')
 
 CASES = [
     (3, 1, 1, True),
@@ -35,10 +30,6 @@ CASES = [
     (3, 1, 0, False),
     ((1, 3, 3), 1, 0, True),
 ]
-ENCODER_CHAIN = [(3, 1, 1, True), (3, 2, 1, False), (3, 1, 1, True), (3, 2, 1, False),
-                 (3, 1, 1, True), (3, 2, (0, 1, 1), False), (3, 1, 1, True),
-                 ((3, 1, 1), (2, 1, 1), 0, False)]
-
 
 @pytest.fixture(scope='module')
 def ref():
@@ -115,17 +106,6 @@ def test_edge_inputs(ref, oracle):
                                  ref_pairs(ref, oracle, idx, 1, SMALL_SHAPE, ks, st, pd, subm))
 
 
-def rulebook_digest(outids, pairs, num):
-    """sha256 over the CPU-reference-ordered rulebook: indiceNum, outids, and the used prefix of
-    every (in, out) pair row.  Shared with the full-size GPU parity tests."""
-    h = hashlib.sha256()
-    h.update(np.ascontiguousarray(num, np.int32).tobytes())
-    h.update(np.ascontiguousarray(outids, np.int32).tobytes())
-    for k in range(pairs.shape[0]):
-        h.update(np.ascontiguousarray(pairs[k, :, :int(num[k])], np.int32).tobytes())
-    return h.hexdigest()
-
-
 def test_full_size_frame_and_committed_digests(ref, oracle):
     """nuScenes-shaped frame 0 at 41x1440x1440 through all 8 rulebooks: oracle == compiled
     reference, and == the digests committed in tests/golden/fullsize_rulebooks.json (written by
@@ -136,8 +116,7 @@ def test_full_size_frame_and_committed_digests(ref, oracle):
     _, c, _ = oracle.hard_voxelize(pts, cfg['voxel_size'], cfg['point_cloud_range'], 10, 160000)
     idx = oracle.batch_coors([c])
     shape = list(configs.NUSC['pts_middle_encoder']['sparse_shape'])
-    with open(os.path.join(GOLD, 'fullsize_rulebooks.json')) as f:
-        gold = json.load(f)['nusc_frame0']
+    gold = fullsize_golden()['nusc_frame0']
     for i, (ks, st, pd, subm) in enumerate(ENCODER_CHAIN):
         a = oracle.get_indice_pairs(idx, 1, shape, ks, st, pd, 1, subm)
         assert_same_rulebook(a, ref_pairs(ref, oracle, idx, 1, shape, ks, st, pd, subm))
