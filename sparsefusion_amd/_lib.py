@@ -136,3 +136,27 @@ def require(t, dtype, what):
     if t.dtype != dtype:
         raise RuntimeError(f'{what} must be {dtype}, got {t.dtype}')
     return t
+
+
+class _ForwardOnly(torch.autograd.Function):
+    """Identity whose backward raises: the kernels behind this library are forward-only (the LiDAR
+    branch is frozen in the target configs), and an output without a grad_fn would let
+    loss.backward() skip these weights without a word."""
+
+    @staticmethod
+    def forward(ctx, out, *deps):
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        raise NotImplementedError(
+            'sparsefusion_amd kernels are forward-only: freeze these parameters '
+            '(requires_grad_(False)) or run under torch.no_grad()')
+
+
+def forward_only(out, *deps):
+    """Tie `out` (a tensor the C ABI wrote) to the tensors it was computed from, so that autograd
+    reaches a backward that raises NotImplementedError instead of silently passing them by."""
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in deps):
+        return _ForwardOnly.apply(out, *deps)
+    return out

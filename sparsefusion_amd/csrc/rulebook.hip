@@ -649,6 +649,7 @@ extern "C" int sf_conv_output_set(const int *indices, const int *n_dev, int n_bo
   Geo g;
   int rc = make_geo(nullptr, out_shape, ksize, stride, padding, batch, &g);
   if (rc != SF_OK) return rc;
+  SF_CHECK_ARG(g.K <= 32, "kernel volume %d > 32: the first-toucher mask is one 32-bit word", g.K);
   SF_CHECK_ARG((long long)n_bound * g.K < 0x7FFFFFFFll, "n_bound*K overflows int32");
   size_t need = sf_conv_output_set_workspace(n_bound, out_capacity);
   if (!workspace || workspace_bytes < need) {
@@ -710,6 +711,7 @@ extern "C" int sf_strided_rulebook(const int *indices, const int *n_dev, int n_b
   Geo g;
   int rc = make_geo(nullptr, out_shape, ksize, stride, padding, batch, &g);
   if (rc != SF_OK) return rc;
+  SF_CHECK_ARG(g.K <= 32, "kernel volume %d > 32: the first-toucher mask is one 32-bit word", g.K);
   SF_CHECK_ARG((long long)n_bound * g.K < 0x7FFFFFFFll, "n_bound*K overflows int32");
   const size_t need = sf_strided_rulebook_workspace(n_bound, out_capacity, ksize, stride);
   if (!workspace || workspace_bytes < need) {

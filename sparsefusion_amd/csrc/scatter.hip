@@ -105,8 +105,9 @@ __global__ void ds_init_kernel(float *__restrict__ vf, int *__restrict__ cnt, lo
 }
 
 __device__ __forceinline__ void atomic_max_f32(float *addr, float v) {
-  // order-preserving integer views of IEEE floats; the slot starts at -inf
-  if (v >= 0.0f)
+  // order-preserving integer views of IEEE floats; the slot starts at -inf.  The branch is on the
+  // SIGN BIT: -0.0f compares >= 0 but its pattern (INT_MIN) would lose a signed max against -inf
+  if (__float_as_int(v) >= 0)
     atomicMax(reinterpret_cast<int *>(addr), __float_as_int(v));
   else
     atomicMin(reinterpret_cast<unsigned *>(addr), __float_as_uint(v));

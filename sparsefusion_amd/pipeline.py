@@ -362,6 +362,11 @@ class LidarBackbone:
             v = self.vfe
             deco = (1 if v._with_cluster_center else 0) | (2 if v._with_voxel_center else 0) | 8
             cur, cur_c = self.voxels, self.F
+            from .voxel_encoder import decorated_channels
+            if decorated_channels(self.F, deco) != v.vfe_layers[0].linear.in_features:
+                raise RuntimeError(f'points have {self.F} features (+ decorations = '
+                                   f'{decorated_channels(self.F, deco)}) but the voxel encoder '
+                                   f'expects {v.vfe_layers[0].linear.in_features} input channels')
             for i, (lay, (w, sc, sh)) in enumerate(zip(v.vfe_layers, self.vfe_params)):
                 chk(L.sf_vfe_layer(
                     cur.data_ptr(), cur_c, self.mp, self.num_points.data_ptr(),

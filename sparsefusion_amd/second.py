@@ -158,7 +158,8 @@ def conv_bn_relu(x, conv, bn, relu, cache, out=None, channel_offset=0):
         if relu:
             y = torch.relu_(y)
         view.copy_(y)
-    return out
+    return _lib.forward_only(out, x, conv.weight, conv.bias,
+                             *((bn.weight, bn.bias) if bn is not None else ()))
 
 
 def _run_sequential(seq, x, caches, out=None, channel_offset=0):

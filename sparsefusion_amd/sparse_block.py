@@ -52,9 +52,11 @@ class SparseBasicBlock(spconv.SparseModule):
         assert x.features.dim() == 2, f'x.features.dim()={x.features.dim()}'
         if spconv._bn_foldable(self.norm1) and spconv._bn_foldable(self.norm2):
             s1, b1 = spconv.fold_bn(self.norm1)
-            out = self.conv1.forward_fused(x, s1, b1, None, True)
+            out = self.conv1.forward_fused(x, s1, b1, None, True,
+                                           bn_params=(self.norm1.weight, self.norm1.bias))
             s2, b2 = spconv.fold_bn(self.norm2)
-            return self.conv2.forward_fused(out, s2, b2, identity, True)
+            return self.conv2.forward_fused(out, s2, b2, identity, True,
+                                            bn_params=(self.norm2.weight, self.norm2.bias))
         out = self.conv1(x)
         out = replace_feature(out, self.relu(self.norm1(out.features)))
         out = self.conv2(out)

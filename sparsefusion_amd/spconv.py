@@ -388,13 +388,15 @@ def _padded_features(features, cin):
 
 
 def sparse_conv(features, packed_filters, cin, cout, rulebook, scale=None, shift=None,
-                residual=None, relu=False, out_dtype=None):
+                residual=None, relu=False, out_dtype=None, params=()):
     """One fused layer: conv (+ folded BN scale/shift) (+ residual) (+ ReLU).  fp32 features run
     the exact-fp32 kernel; bf16 features (with bf16-packed filters) the bf16 MFMA kernel, whose
     output is bf16 unless out_dtype=torch.float32."""
     L = _lib.lib()
     if features.shape[0] != rulebook.in_coords.n:
         raise RuntimeError('features rows do not match the rulebook input set')
+    # `params`: the nn.Parameters the packed filters / folded scale and shift were derived from
+    grad_deps = (features, residual) + tuple(params)
     if features.dtype == torch.bfloat16:
         _lib.require(packed_filters, torch.bfloat16, 'packed filters')
         x, cp = _padded_features_bf16(features, cin)
@@ -412,7 +414,7 @@ def sparse_conv(features, packed_filters, cin, cout, rulebook, scale=None, shift
             rulebook.k_first, _lib.ptr(packed_filters), cout, _lib.ptr(scale), _lib.ptr(shift),
             _lib.ptr(residual), 1 if relu else 0, out.data_ptr(), 1 if odt == torch.float32 else 0,
             None, n_out, _lib.stream(features.device)))
-        return out
+        return _lib.forward_only(out, *grad_deps)
     _lib.require(features, torch.float32, 'features')
     if out_dtype not in (None, torch.float32):
         raise RuntimeError('fp32 features give fp32 output (cast with cast_bf16)')
@@ -429,13 +431,13 @@ def sparse_conv(features, packed_filters, cin, cout, rulebook, scale=None, shift
             rulebook.k_first, rulebook.row_order().data_ptr(), _lib.ptr(packed_filters), cout,
             _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(residual), 1 if relu else 0, out.data_ptr(),
             None, n_out, _lib.stream(features.device)))
-        return out
+        return _lib.forward_only(out, *grad_deps)
     _lib.check(L.sf_sparse_conv_f32(
         _lib.ptr(x), cp, rulebook.nbr.data_ptr(), rulebook.nbr.shape[1], rulebook.K,
         rulebook.k_first, _lib.ptr(packed_filters), cout, _lib.ptr(scale), _lib.ptr(shift),
         _lib.ptr(residual), 1 if relu else 0, out.data_ptr(), None, n_out,
         _lib.stream(features.device)))
-    return out
+    return _lib.forward_only(out, *grad_deps)
 
 
 def indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_out, inverse=False,
@@ -461,7 +463,7 @@ def indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_o
     _lib.check(L.sf_sparse_conv_f32(_lib.ptr(x), cp, nbr.data_ptr(), stride_rows, K, k_first,
                                     packed.data_ptr(), cout, None, None, None, 0, out.data_ptr(),
                                     None, n_out, _lib.stream(dev)))
-    return out
+    return _lib.forward_only(out, features, filters)
 
 
 # ------------------------------------------------------------------ modules
@@ -565,7 +567,9 @@ class SparseConvolution(SparseModule):
         return rb
 
     def forward_fused(self, input, scale=None, shift=None, residual=None, relu=False,
-                      out_dtype=None):
+                      out_dtype=None, bn_params=()):
+        """bn_params: the BatchNorm affine parameters folded into scale / shift, so that autograd
+        sees them (the op is forward-only: its backward raises)."""
         assert isinstance(input, SparseConvTensor)
         rb = self.rulebook_for(input)
         if self.bias is not None:
@@ -575,7 +579,7 @@ class SparseConvolution(SparseModule):
                 scale = torch.ones_like(b)
         feats = sparse_conv(input.features, self.packed_filters(input.features.dtype),
                             self.in_channels, self.out_channels, rb, scale, shift, residual, relu,
-                            out_dtype)
+                            out_dtype, params=(self.weight, self.bias) + tuple(bn_params))
         out = SparseConvTensor(feats, rb.out_coords.indices, rb.out_coords.spatial_shape,
                                input.batch_size, input.grid)
         out.indice_dict = input.indice_dict
@@ -661,7 +665,8 @@ class SparseSequential(SparseModule):
                 relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
                 last = i + (3 if relu else 2) >= len(mods)
                 input = m.forward_fused(input, scale, shift, None, relu,
-                                        out_dtype if last else None)
+                                        out_dtype if last else None,
+                                        bn_params=(mods[i + 1].weight, mods[i + 1].bias))
                 i += 3 if relu else 2
             elif isinstance(m, SparseModule):
                 assert isinstance(input, SparseConvTensor)

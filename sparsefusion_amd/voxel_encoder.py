@@ -29,6 +29,14 @@ class HardSimpleVFE(nn.Module):
         return out
 
 
+def decorated_channels(cin_raw, decorate):
+    """Input width of sf_vfe_layer's Linear for `cin_raw` raw channels and the decorate bits
+    (include/sparsefusion_hip.h: 1 cluster centre +3, 2 voxel centre +3 (+2 with bit 16), 4
+    distance +1)."""
+    return cin_raw + 3 * (decorate & 1) + ((2 if decorate & 16 else 3) if decorate & 2 else 0) + \
+        (1 if decorate & 4 else 0)
+
+
 class VFELayer(nn.Module):
     """mmdet3d/models/voxel_encoders/utils.py:31-96: Linear(bias=False) -> BN1d -> ReLU -> max over
     the points of a voxel [-> concat].  Same attributes / state-dict keys (`linear`, `norm`)."""
@@ -51,6 +59,12 @@ class VFELayer(nn.Module):
                                       'is frozen in the target configs)')
         m, p, c = inputs.shape
         cout = self.linear.out_features
+        # the kernel derives its input width from the raw channels and the decorate bits and
+        # indexes the (cout, cin) weight with it: a mismatch must fail here, as nn.Linear would
+        cin = decorated_channels(c, decorate)
+        if cin != self.linear.in_features:
+            raise RuntimeError(f'VFE layer expects {self.linear.in_features} input channels, got '
+                               f'{c} raw + {cin - c} decoration channels = {cin}')
         scale, shift = spconv.fold_bn(self.norm)
         mode = 1 if not self.max_out else (2 if self.cat_max else 0)
         shape = {0: (m, cout), 1: (m, p, cout), 2: (m, p, 2 * cout)}[mode]
@@ -63,7 +77,7 @@ class VFELayer(nn.Module):
             _lib.f6(pc_range) if pc_range is not None else None,
             _lib.ptr(self.linear.weight.detach().float().contiguous()), cout, _lib.ptr(scale),
             _lib.ptr(shift), mode, out.data_ptr(), _lib.stream(inputs.device)))
-        return out
+        return _lib.forward_only(out, inputs, self.linear.weight, self.norm.weight, self.norm.bias)
 
     def forward(self, inputs):
         return self._run(inputs)

@@ -109,3 +109,16 @@ def test_batched_coors(dev, oracle):
                             np.pad(eb[1], ((0, 0), (1, 0)), constant_values=1)])
     assert np.array_equal(vc.cpu().numpy(), exp_c)
     assert np.allclose(vf.cpu().numpy(), np.concatenate([ea[0], eb[0]]), rtol=1e-5, atol=2e-4)
+
+
+def test_max_of_negative_zero_and_all_negative(dev):
+    """A voxel whose only contribution to a channel is -0.0 must come out as -0.0, not the -inf
+    the slot starts from (the reference's atomicMax on floats gives -0.0); all-negative channels
+    give their largest value."""
+    feats = np.asarray([[-0.0, -3.0, 1.0], [-2.5, -1.5, -0.0], [-7.0, -0.5, -4.0]], np.float32)
+    coors = np.asarray([[0, 0, 1], [2, 1, 0], [2, 1, 0]], np.int32)
+    f, c = torch.from_numpy(feats).to(dev), torch.from_numpy(coors).to(dev)
+    vf, vc, m, k = [t.cpu().numpy() for t in dynamic_point_to_voxel_forward(f, c, 'max')]
+    assert vc.tolist() == [[0, 0, 1], [2, 1, 0]]
+    expect = np.asarray([[-0.0, -3.0, 1.0], [-2.5, -0.5, -0.0]], np.float32)
+    assert np.array_equal(vf.view(np.uint32), expect.view(np.uint32))

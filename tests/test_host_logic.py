@@ -101,3 +101,28 @@ def test_registry_builders_resolve_every_mirrored_module():
                                         layer_nums=[1], layer_strides=[1])) is not None
     assert registry.build_neck(dict(type='SECONDFPN', in_channels=[8], out_channels=[8],
                                     upsample_strides=[1])) is not None
+
+
+def test_forward_only_guard_raises_in_backward():
+    """Ops behind the C ABI are forward-only: an output computed from a tensor that requires grad
+    must carry a grad_fn whose backward raises (instead of silently skipping the weights)."""
+    import pytest
+    from sparsefusion_amd import _lib
+    w = torch.nn.Parameter(torch.ones(3))
+    out = torch.zeros(3)                       # stands for a buffer the C ABI wrote
+    y = _lib.forward_only(out, None, w)
+    assert y.requires_grad and y.data_ptr() == out.data_ptr()
+    with pytest.raises(NotImplementedError, match='forward-only'):
+        y.sum().backward()
+    with torch.no_grad():
+        assert _lib.forward_only(out, w) is out
+    w.requires_grad_(False)                    # frozen LiDAR branch: nothing to guard
+    assert _lib.forward_only(out, w) is out
+
+
+def test_vfe_decorated_channels():
+    from sparsefusion_amd.voxel_encoder import decorated_channels
+    assert decorated_channels(5, 8) == 5                   # mask only
+    assert decorated_channels(5, 1 | 2 | 8) == 11          # HardVFE: cluster + voxel centre
+    assert decorated_channels(4, 1 | 2 | 16 | 32 | 8) == 9  # PillarFeatureNet: +3 +2
+    assert decorated_channels(4, 1 | 2 | 4 | 16 | 8) == 10  # ... + distance
