@@ -82,6 +82,28 @@ SF_API int sf_hard_voxelize(const float *points, int n, int f, const float voxel
                             int *overflow_dev, int *voxel_num_host, void *workspace,
                             size_t workspace_bytes, void *stream);
 
+/* Bytes of the static device scratch behind sf_hard_voxelize_static (per GPU). */
+#define SF_STATIC_SCRATCH_BYTES (32u << 20)
+
+/* sf_hard_voxelize for callers that CANNOT ALLOCATE device memory (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference (its op
+ * allocates its temporaries through ATen on every call, voxelization_cuda.cu:196-216).  Same
+ * kernels, same results, same arguments minus the workspace and minus voxel_num_host (read the
+ * count from *row_count_dev): the scratch is a file-scope device array of SF_STATIC_SCRATCH_BYTES
+ * that every GPU the library runs on holds until the process ends.  The call performs no
+ * hipMalloc / hipFree and no host synchronisation.
+ *  Limit: sf_hard_voxelize_workspace(n, max_points) <= SF_STATIC_SCRATCH_BYTES (about 349 000
+ *  points at max_points 10, i.e. a nuScenes-shaped 10-sweep frame), else SF_ERR_WORKSPACE.
+ *  All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two
+ *  host threads) race; serialise them.  Consecutive calls are independent (the scratch is
+ *  re-initialised by each call). */
+SF_API int sf_hard_voxelize_static(const float *points, int n, int f, const float voxel_size[3],
+                                   const float coors_range[6], int max_points, int max_voxels,
+                                   float *voxels, int *coors, int coors_stride, int batch_idx,
+                                   int *num_points_per_voxel, float *mean, int mean_features,
+                                   int mean_stride, int *row_count_dev, int rows_capacity,
+                                   int *overflow_dev, void *stream);
+
 /* Replaces HardSimpleVFE.forward (mmdet3d/models/voxel_encoders/voxel_encoder.py:27-44) on an
  * already materialised voxel tensor: out[v][k] = sum_s voxels[v][s][k] / num_points[v] for
  * k < num_features, columns [num_features, out_stride) zero. */

@@ -28,6 +28,8 @@ SIGNATURES = {
     'sf_hard_voxelize_workspace': (_sz, [_i, _i]),
     'sf_hard_voxelize': (_i, [_vp, _i, _i, _f3, _f6, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i,
                               _vp, _i, _vp, C.POINTER(_i), _vp, _sz, _vp]),
+    'sf_hard_voxelize_static': (_i, [_vp, _i, _i, _f3, _f6, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i,
+                                     _i, _vp, _i, _vp, _vp]),
     'sf_voxel_mean': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     'sf_vfe_layer': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _f3, _f6, _vp, _i, _vp, _vp, _i, _vp,
                           _vp]),

@@ -16,6 +16,8 @@
 //             voxel id equals max_voxels is the cut (reference `break`); writes coors
 //   write   : voxels[v][s][:] = points[list[s]] for list entries below the cut, zeros elsewhere
 //   reduce  : num_points_per_voxel and the fused HardSimpleVFE mean
+#include <mutex>
+
 #include "sf_common.h"
 
 namespace {
@@ -328,14 +330,16 @@ extern "C" size_t sf_hard_voxelize_workspace(int n, int max_points) {
   return carve(nullptr, n, max_points).bytes;
 }
 
-extern "C" int sf_hard_voxelize(const float *points, int n, int f, const float voxel_size[3],
-                                const float coors_range[6], int max_points, int max_voxels,
-                                float *voxels, int *coors, int coors_stride, int batch_idx,
-                                int *num_points_per_voxel, float *mean, int mean_features,
-                                int mean_stride, int *row_count_dev, int rows_capacity,
-                                int *overflow_dev, int *voxel_num_host, void *workspace,
-                                size_t workspace_bytes, void *stream) {
-  hipStream_t st = (hipStream_t)stream;
+namespace {
+
+// Body of both hard-voxelize entry points; `workspace` is device memory of at least
+// carve(nullptr, n, max_points).bytes bytes, whoever owns it.
+int hard_voxelize_impl(const float *points, int n, int f, const float voxel_size[3],
+                       const float coors_range[6], int max_points, int max_voxels, float *voxels,
+                       int *coors, int coors_stride, int batch_idx, int *num_points_per_voxel,
+                       float *mean, int mean_features, int mean_stride, int *row_count_dev,
+                       int rows_capacity, int *overflow_dev, int *voxel_num_host, void *workspace,
+                       size_t workspace_bytes, hipStream_t st) {
   SF_CHECK_ARG(n >= 0 && f >= 3, "bad shape n=%d f=%d (need f >= 3)", n, f);
   SF_CHECK_ARG(max_points >= 1, "max_points=%d: the hard path needs max_points >= 1 "
                "(use sf_dynamic_voxelize for -1)", max_points);
@@ -394,6 +398,76 @@ extern "C" int sf_hard_voxelize(const float *points, int n, int f, const float v
     SF_CHECK_HIP(hipStreamSynchronize(st));
   }
   return SF_OK;
+}
+
+// ---- scratch of the allocation-free entry point (sf_hard_voxelize_static) ---------------------
+// One array per GPU the library is loaded on, held until the process ends.  In HOST code the
+// name `scratch` is only a handle for hipGetSymbolAddress: it is not a device address and must
+// never be passed to a kernel or a HIP memory call.  Host code uses the per-device pointer that
+// static_scratch() returns.
+constexpr size_t kStaticScratchBytes = (size_t)SF_STATIC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+void *g_scratch_ptr[kMaxDevices] = {};   // device address of `scratch`, per device ordinal
+
+// Device address of the CURRENT device's copy of `scratch`; resolved once per device (a symbol
+// lookup: no allocation), then served from the table.
+int static_scratch(void **ptr) {
+  int dev = -1;
+  SF_CHECK_HIP(hipGetDevice(&dev));
+  SF_CHECK_ARG(dev >= 0 && dev < kMaxDevices, "device ordinal %d out of range", dev);
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[dev]) {
+    void *p = nullptr;
+    SF_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    SF_CHECK_ARG(p != nullptr, "hipGetSymbolAddress returned NULL for the static scratch");
+    g_scratch_ptr[dev] = p;
+  }
+  *ptr = g_scratch_ptr[dev];
+  return SF_OK;
+}
+
+}  // namespace
+
+extern "C" int sf_hard_voxelize(const float *points, int n, int f, const float voxel_size[3],
+                                const float coors_range[6], int max_points, int max_voxels,
+                                float *voxels, int *coors, int coors_stride, int batch_idx,
+                                int *num_points_per_voxel, float *mean, int mean_features,
+                                int mean_stride, int *row_count_dev, int rows_capacity,
+                                int *overflow_dev, int *voxel_num_host, void *workspace,
+                                size_t workspace_bytes, void *stream) {
+  return hard_voxelize_impl(points, n, f, voxel_size, coors_range, max_points, max_voxels, voxels,
+                            coors, coors_stride, batch_idx, num_points_per_voxel, mean,
+                            mean_features, mean_stride, row_count_dev, rows_capacity, overflow_dev,
+                            voxel_num_host, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int sf_hard_voxelize_static(const float *points, int n, int f,
+                                       const float voxel_size[3], const float coors_range[6],
+                                       int max_points, int max_voxels, float *voxels, int *coors,
+                                       int coors_stride, int batch_idx, int *num_points_per_voxel,
+                                       float *mean, int mean_features, int mean_stride,
+                                       int *row_count_dev, int rows_capacity, int *overflow_dev,
+                                       void *stream) {
+  SF_CHECK_ARG(n >= 0 && max_points >= 1, "bad n=%d / max_points=%d", n, max_points);
+  const size_t need = carve(nullptr, n, max_points).bytes;
+  if (need > kStaticScratchBytes) {
+    sf_set_error("sf_hard_voxelize_static: %d points x max_points %d need %zu bytes of scratch, the "
+                 "static buffer holds %zu (use sf_hard_voxelize with a caller workspace)",
+                 n, max_points, need, kStaticScratchBytes);
+    return SF_ERR_WORKSPACE;
+  }
+  void *ws = nullptr;
+  int rc = static_scratch(&ws);
+  if (rc != SF_OK) return rc;
+  // every word the kernels read is (re)initialised by vox_fill / written earlier in the same call,
+  // so the previous call's contents never leak into this one
+  return hard_voxelize_impl(points, n, f, voxel_size, coors_range, max_points, max_voxels, voxels,
+                            coors, coors_stride, batch_idx, num_points_per_voxel, mean,
+                            mean_features, mean_stride, row_count_dev, rows_capacity, overflow_dev,
+                            nullptr, ws, kStaticScratchBytes, (hipStream_t)stream);
 }
 
 extern "C" int sf_voxel_mean(const float *voxels, const int *num_points_per_voxel, const int *m_dev,
