@@ -18,7 +18,7 @@
 
 #include <type_traits>
 
-#include "sf_common.h"
+#include "spconv_internal.h"
 
 namespace {
 
@@ -911,17 +911,7 @@ __global__ void pad_channels_kernel(const float *__restrict__ src, int cs, float
 unsigned long long *g_conv_prof = nullptr;  // diagnostic only, see sf_debug_conv_profile
 const int *g_row_order = nullptr;            // experiment hook, see sf_debug_conv_row_order
 
-struct ConvArgs {
-  const float *feat;
-  const int *nbr;
-  int nbr_stride, K, k_first;
-  const float *wpk, *scale, *shift, *residual;
-  int relu;
-  float *out;
-  const int *n_out_dev;
-  int n_out_bound;
-  hipStream_t st;
-};
+using ConvArgs = SfConvArgs;
 
 // Balanced tiling pays where a layer has only ~2 tiles per resident workgroup (the 128-channel
 // stage: 33k rows / 64 = 520 tiles on 256 CUs); SF_CONV_BALANCE=0/1 overrides for experiments.
@@ -1131,6 +1121,16 @@ int launch_cfg(const ConvArgs &a) {
 #undef SF_CASE
 #undef SF_CASE_W
 
+// Experiment hook: SF_CONV_NARROW=0 sends the narrow layers to the older direct kernel (A/B runs).
+bool env_legacy_narrow() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("SF_CONV_NARROW");
+    v = (e && atoi(e) == 0) ? 1 : 0;
+  }
+  return v == 1;
+}
+
 template <int CIN>
 int dispatch_cout(int cout, const ConvArgs &a) {
   switch (cout) {
@@ -1199,6 +1199,10 @@ extern "C" int sf_sparse_conv_f32(const float *features_in, int cin_padded, cons
                "feature / filter / epilogue pointers must be 16-byte aligned");
   ConvArgs a{features_in, nbr, nbr_stride, K, k_first, w_packed, scale, shift, residual, relu, out,
              n_out_dev, n_out_bound, st};
+  if (!env_legacy_narrow()) {  // the narrow 3x3x3 layers have a kernel of their own
+    const int rc = sf_narrow_conv_f32(cin_padded, cout, a);
+    if (rc <= 0) return rc;
+  }
   switch (cin_padded) {
     case 8: return dispatch_cout<8>(cout, a);
     case 16: return dispatch_cout<16>(cout, a);

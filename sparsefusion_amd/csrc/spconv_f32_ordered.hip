@@ -29,8 +29,6 @@
 //     stores straight from the accumulators after the folded BN / residual / ReLU epilogue.
 // Per output element the FMA chain is: centre offset, then offsets ascending, channels ascending
 // -- fixed, no atomics, independent of the row order.
-#include <hipcub/hipcub.hpp>
-
 #include "sf_common.h"
 
 namespace {
@@ -54,19 +52,171 @@ struct ATileF {
   __device__ static __forceinline__ int pos(int p, int c) { return c ^ ((p / R) & M); }
 };
 
+// ---- row order: stable LSD radix sort of (27-bit mask, row), 3 passes of 9 bits ------------------
+// Hand-written (no library call on the path): every kernel is bounded by the DEVICE-side row count
+// (blocks past it exit at once), so a rulebook sized for its 8x geometric bound costs what its
+// real rows cost.
+constexpr int kSortChunk = 2048;   // keys per 256-thread block: 4 waves x 8 batches of 64
+constexpr int kSortBins = 512;     // 9-bit digits
+constexpr int kTileRows = 64;      // rows per tile of the ordered kernels (schedule granularity)
+
 __global__ void row_mask_kernel(const int *__restrict__ nbr, int nbr_stride, int K,
-                                const int *n_dev, int n_bound, unsigned *__restrict__ keys,
-                                int *__restrict__ rows) {
+                                const int *n_dev, int n_bound, unsigned *__restrict__ keys) {
   const int n = load_n(n_dev, n_bound);
-  for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < n_bound; o += gridDim.x * blockDim.x) {
+  const int n_round = (n + kSortChunk - 1) / kSortChunk * kSortChunk;  // whole chunks are sorted
+  const int end = n_round < n_bound ? n_round : n_bound;
+  for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < end; o += gridDim.x * blockDim.x) {
     unsigned m = 0xFFFFFFFFu;  // rows past the count sort behind every real row
     if (o < n) {
       m = 0;
       for (int k = 0; k < K; ++k) m |= (unsigned)(nbr[(size_t)k * nbr_stride + o] >= 0) << k;
     }
     keys[o] = m;
-    rows[o] = o;
   }
+}
+
+// pass 1 of a digit: per-block histogram, hist[bin * nblk_bound + block]
+__global__ void __launch_bounds__(256)
+sort_hist_kernel(const unsigned *__restrict__ keys, const int *n_dev, int n_bound, int shift,
+                 int nblk_bound, int *__restrict__ hist) {
+  __shared__ int s_h[kSortBins];
+  const int n = load_n(n_dev, n_bound);
+  const int base = blockIdx.x * kSortChunk;
+  if (base >= n) return;
+  for (int i = threadIdx.x; i < kSortBins; i += 256) s_h[i] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < kSortChunk; i += 256) {
+    const int o = base + i;
+    const unsigned key = o < n_bound ? keys[o] : 0xFFFFFFFFu;
+    atomicAdd(&s_h[(key >> shift) & (kSortBins - 1)], 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kSortBins; i += 256) hist[(size_t)i * nblk_bound + blockIdx.x] = s_h[i];
+}
+
+// pass 2: exclusive scan of the (bin-major, block-minor) histogram over the ACTIVE blocks, one
+// 1024-thread workgroup
+__global__ void __launch_bounds__(1024)
+sort_scan_kernel(const int *n_dev, int n_bound, int nblk_bound, int *__restrict__ hist) {
+  __shared__ int smem[17];
+  const int n = load_n(n_dev, n_bound);
+  const int nblk = (n + kSortChunk - 1) / kSortChunk;
+  const int total = nblk * kSortBins;
+  const int per = (total + 1023) / 1024;
+  const int lo = threadIdx.x * per, hi = (lo + per < total) ? lo + per : total;
+  int sum = 0;
+  for (int e = lo; e < hi; ++e) sum += hist[(size_t)(e / nblk) * nblk_bound + e % nblk];
+  int tot;
+  int run = sf_block_excl_scan(sum, smem, &tot);
+  for (int e = lo; e < hi; ++e) {
+    int *p = &hist[(size_t)(e / nblk) * nblk_bound + e % nblk];
+    const int v = *p;
+    *p = run;
+    run += v;
+  }
+}
+
+// pass 3: stable scatter.  A wave owns 512 consecutive keys of the block's chunk and places them
+// batch by batch (64 at a time, in order); lanes of one batch that share a digit are ranked by
+// lane (a match over the 9 digit bits).
+__global__ void __launch_bounds__(256)
+sort_scatter_kernel(const unsigned *__restrict__ keys, const int *__restrict__ rows,
+                    const int *n_dev, int n_bound, int shift, int nblk_bound,
+                    const int *__restrict__ hist, unsigned *__restrict__ keys_out,
+                    int *__restrict__ rows_out) {
+  __shared__ int s_h[4][kSortBins];
+  const int n = load_n(n_dev, n_bound);
+  const int base = blockIdx.x * kSortChunk;
+  if (base >= n) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 4 * kSortBins; i += 256) (&s_h[0][0])[i] = 0;
+  __syncthreads();
+  unsigned key[8];
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const int o = base + wave * 512 + b * 64 + lane;
+    key[b] = o < n_bound ? keys[o] : 0xFFFFFFFFu;
+    atomicAdd(&s_h[wave][(key[b] >> shift) & (kSortBins - 1)], 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kSortBins; i += 256) {
+    int run = hist[(size_t)i * nblk_bound + blockIdx.x];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int c = s_h[w][i];
+      s_h[w][i] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+  const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const int o = base + wave * 512 + b * 64 + lane;
+    const int d = (int)((key[b] >> shift) & (kSortBins - 1));
+    unsigned long long m = ~0ull;
+#pragma unroll
+    for (int bit = 0; bit < 9; ++bit) {
+      const unsigned long long bal = __ballot((d >> bit) & 1);
+      m &= ((d >> bit) & 1) ? bal : ~bal;
+    }
+    const int rank = __popcll(m & lt);
+    volatile int *cursor = &s_h[wave][d];
+    const int pos = *cursor + rank;
+    __builtin_amdgcn_wave_barrier();
+    if (rank == 0) *cursor = pos + __popcll(m);
+    __builtin_amdgcn_wave_barrier();
+    if (o < n_bound && pos < n_bound) {
+      keys_out[pos] = key[b];
+      rows_out[pos] = rows ? rows[o] : o;
+    }
+  }
+}
+
+// Work of every tile of kTileRows sorted rows = number of (16-row block, offset) products it
+// needs; one wave per tile.
+__global__ void __launch_bounds__(256)
+tile_weight_kernel(const unsigned *__restrict__ keys_sorted, const int *n_dev, int n_bound,
+                   int *__restrict__ weight) {
+  const int n = load_n(n_dev, n_bound);
+  const int tiles = (n + kTileRows - 1) / kTileRows;
+  const int lane = threadIdx.x & 63;
+  for (int t = blockIdx.x * 4 + (threadIdx.x >> 6); t < tiles; t += gridDim.x * 4) {
+    const int e = t * kTileRows + lane;
+    unsigned m = e < n ? (keys_sorted[e] & 0x7FFFFFFu) : 0u;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) m |= (unsigned)__shfl_xor((int)m, d, 64);
+    int w = (lane & 15) == 0 ? __popc(m) : 0;
+    w += __shfl_xor(w, 16, 64);
+    w += __shfl_xor(w, 32, 64);
+    if (lane == 0) weight[t] = w;
+  }
+}
+
+// Tile schedule = tiles by descending work (counting sort over the <= 109 distinct weights, one
+// workgroup).  Dealt to the persistent workgroups in snake order it is a longest-processing-time
+// assignment: the heaviest tiles are spread first, the light ones level the tails.
+__global__ void __launch_bounds__(1024)
+tile_schedule_kernel(const int *__restrict__ weight, const int *n_dev, int n_bound,
+                     int *__restrict__ sched) {
+  __shared__ int s_cnt[128];
+  const int n = load_n(n_dev, n_bound);
+  const int tiles = (n + kTileRows - 1) / kTileRows;
+  if (threadIdx.x < 128) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  for (int t = threadIdx.x; t < tiles; t += 1024) atomicAdd(&s_cnt[127 - weight[t]], 1);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int i = 0; i < 128; ++i) {
+      const int c = s_cnt[i];
+      s_cnt[i] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+  // equal weights keep no particular order (the schedule affects timing only, never results)
+  for (int t = threadIdx.x; t < tiles; t += 1024) sched[atomicAdd(&s_cnt[127 - weight[t]], 1)] = t;
 }
 
 template <int CIN, int COUT, int TM, int CG, int WAVES, int MINB>
@@ -102,8 +252,15 @@ conv_f32_ordered_kernel(const float *__restrict__ feat, unsigned feat_bytes,
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(feat), 0, feat_bytes, 0x00020000);
   const int kf = (k_first >= 0 && k_first < K) ? k_first : -1;
   const int tiles = (n_out + TM - 1) / TM;
+  // tiles in the schedule's order (descending work), dealt to the persistent workgroups in snake
+  // order: round j gives workgroup b entry j*G + b (even j) or j*G + G-1-b (odd j)
+  const int *__restrict__ sched = order ? order + n_out_bound : nullptr;
+  const int G = gridDim.x;
 
-  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+  for (int j = 0; j * G < tiles; ++j) {
+    const int slot = j * G + ((j & 1) ? G - 1 - (int)blockIdx.x : (int)blockIdx.x);
+    if (slot >= tiles) continue;
+    const int tile = sched ? sched[slot] : slot;
     const int row0 = tile * TM;
     // ---- setup ------------------------------------------------------------------------
     if (tid < TM) {
@@ -287,8 +444,20 @@ int launch_ordered(const OrdArgs &a) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
+  static_assert(TM == kTileRows, "the tile schedule is built for kTileRows-row tiles");
+  static int slots = 0;          // resident workgroups on the device
+  if (slots == 0) {
+    int dev = 0, cus = 256, per_cu = 1;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, WAVES * 64, lds) != hipSuccess ||
+        per_cu < 1)
+      per_cu = 1;
+    slots = cus * per_cu;
+  }
   const int tiles = sf_div_up(a.n_out_bound, TM);
-  const int grid = tiles < 8192 ? tiles : 8192;
+  const int grid = tiles < slots ? tiles : slots;
   hipLaunchKernelGGL(kern, dim3(grid),
                      dim3(WAVES * 64), lds, a.st, a.feat, a.feat_bytes, a.nbr, a.nbr_stride, a.K,
                      a.k_first, a.order, reinterpret_cast<const f32x4 *>(a.wpk), a.scale, a.shift,
@@ -315,13 +484,22 @@ int dispatch_ordered(int cout, const OrdArgs &a) {
 
 }  // namespace
 
+namespace {
+size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+int sort_blocks(int n_bound) { return sf_div_up(n_bound > 0 ? n_bound : 1, kSortChunk); }
+}  // namespace
+
 extern "C" size_t sf_row_order_workspace(int n_bound) {
   if (n_bound < 1) n_bound = 1;
-  size_t tmp = 0;
-  hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, (const unsigned *)nullptr, (unsigned *)nullptr,
-                                     (const int *)nullptr, (int *)nullptr, n_bound, 0, 32, 0);
-  const size_t arr = ((size_t)n_bound * 4 + 255) & ~(size_t)255;
-  return 3 * arr + ((tmp + 255) & ~(size_t)255);
+  const size_t arr = align_up((size_t)n_bound * 4);
+  const size_t tiles = (size_t)sf_div_up(n_bound, kTileRows);
+  // keys x2, rows x2, per-block histograms, tile weights
+  return 4 * arr + align_up((size_t)sort_blocks(n_bound) * kSortBins * 4) + align_up(tiles * 4);
+}
+
+extern "C" int sf_row_order_size(int n_bound) {
+  if (n_bound < 1) n_bound = 1;
+  return n_bound + sf_div_up(n_bound, kTileRows);
 }
 
 extern "C" int sf_row_order_by_mask(const int *nbr, int nbr_stride, int K, const int *n_dev,
@@ -337,17 +515,39 @@ extern "C" int sf_row_order_by_mask(const int *nbr, int nbr_stride, int K, const
                  sf_row_order_workspace(n_bound));
     return SF_ERR_WORKSPACE;
   }
-  const size_t arr = ((size_t)n_bound * 4 + 255) & ~(size_t)255;
+  const size_t arr = align_up((size_t)n_bound * 4);
+  const int nblk = sort_blocks(n_bound);
   char *ws = (char *)workspace;
-  unsigned *keys = (unsigned *)ws, *keys_out = (unsigned *)(ws + arr);
-  int *rows = (int *)(ws + 2 * arr);
-  void *tmp = ws + 3 * arr;
-  size_t tmp_bytes = workspace_bytes - 3 * arr;
+  unsigned *keys0 = (unsigned *)ws, *keys1 = (unsigned *)(ws + arr);
+  int *rows0 = (int *)(ws + 2 * arr), *rows1 = (int *)(ws + 3 * arr);
+  int *hist = (int *)(ws + 4 * arr);
+  int *weight = (int *)(ws + 4 * arr + align_up((size_t)nblk * kSortBins * 4));
+  int *sched = row_order + n_bound;
   hipLaunchKernelGGL(row_mask_kernel, dim3(sf_grid(n_bound, 256)), dim3(256), 0, st, nbr, nbr_stride,
-                     K, n_dev, n_bound, keys, rows);
+                     K, n_dev, n_bound, keys0);
   SF_CHECK_LAUNCH();
-  SF_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys_out, rows, row_order,
-                                                  n_bound, 0, 32, st));
+  // three stable passes over the 27 mask bits; the last one lands in row_order
+  const unsigned *kin[3] = {keys0, keys1, keys0};
+  unsigned *kout[3] = {keys1, keys0, keys1};
+  const int *rin[3] = {nullptr, rows1, rows0};   // pass 0 starts from the identity
+  int *rout[3] = {rows1, rows0, row_order};
+  for (int p = 0; p < 3; ++p) {
+    hipLaunchKernelGGL(sort_hist_kernel, dim3(nblk), dim3(256), 0, st, kin[p], n_dev, n_bound, 9 * p,
+                       nblk, hist);
+    SF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(1024), 0, st, n_dev, n_bound, nblk, hist);
+    SF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sort_scatter_kernel, dim3(nblk), dim3(256), 0, st, kin[p], rin[p], n_dev,
+                       n_bound, 9 * p, nblk, (const int *)hist, kout[p], rout[p]);
+    SF_CHECK_LAUNCH();
+  }
+  const int tiles = sf_div_up(n_bound, kTileRows);
+  hipLaunchKernelGGL(tile_weight_kernel, dim3(sf_grid(tiles, 4)), dim3(256), 0, st,
+                     (const unsigned *)keys1, n_dev, n_bound, weight);
+  SF_CHECK_LAUNCH();
+  hipLaunchKernelGGL(tile_schedule_kernel, dim3(1), dim3(1024), 0, st, (const int *)weight, n_dev,
+                     n_bound, sched);
+  SF_CHECK_LAUNCH();
   return SF_OK;
 }
 

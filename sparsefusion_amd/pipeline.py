@@ -188,7 +188,7 @@ class LidarBackbone:
             lay.ordered = (not lay.bf16) and spconv.use_ordered(L.sf_conv_padded_cin(lay.cin), lay.cout)
             if lay.ordered and 'order' not in lay.rb:
                 nb_rows = self.sets[lay.rb['dst']]['bound']
-                lay.rb['order'] = i32(nb_rows)
+                lay.rb['order'] = i32(L.sf_row_order_size(nb_rows))
                 lay.rb['order_ws_bytes'] = L.sf_row_order_workspace(nb_rows)
                 lay.rb['order_ws'] = torch.empty(lay.rb['order_ws_bytes'], dtype=torch.uint8,
                                                  device=dev)

@@ -91,7 +91,7 @@ class Rulebook:
             L = _lib.lib()
             n = max(self.out_coords.n, 1)
             dev = self.nbr.device
-            order = torch.empty(n, dtype=torch.int32, device=dev)
+            order = torch.empty(L.sf_row_order_size(n), dtype=torch.int32, device=dev)
             wsb = L.sf_row_order_workspace(n)
             ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
             _lib.check(L.sf_row_order_by_mask(self.nbr.data_ptr(), self.nbr.shape[1], self.K, None,

@@ -21,7 +21,7 @@ def _coords(oracle, seed, n, batch=1):
 def _row_order(rb, dev):
     L = _lib.lib()
     n = rb.out_coords.n
-    order = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    order = torch.empty(L.sf_row_order_size(max(n, 1)), dtype=torch.int32, device=dev)
     wsb = L.sf_row_order_workspace(max(n, 1))
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     _lib.check(L.sf_row_order_by_mask(rb.nbr.data_ptr(), rb.nbr.shape[1], rb.K, None, n,
@@ -43,6 +43,15 @@ def test_row_order_is_a_mask_sorted_permutation(dev, oracle, subm, ks, st, pd):
     assert np.all(np.diff(m) >= 0)                                   # sorted by mask
     same = np.diff(m) == 0
     assert np.all(np.diff(order[:n])[same] > 0)                       # stable inside a mask
+    # the tile schedule behind the order: every 64-row tile once, by descending work
+    tiles = (n + 63) // 64
+    sched = order[n:n + tiles]
+    assert np.array_equal(np.sort(sched), np.arange(tiles))
+    pad = np.zeros(tiles * 64, np.int64)
+    pad[:n] = m
+    blocks = np.bitwise_or.reduce(pad.reshape(-1, 16), axis=1)
+    work = np.array([bin(int(b)).count('1') for b in blocks]).reshape(tiles, 4).sum(1)
+    assert np.all(np.diff(work[sched]) <= 0)
 
 
 @pytest.mark.parametrize('cin,cout,subm,ks,st,pd', [
