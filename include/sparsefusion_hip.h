@@ -284,13 +284,18 @@ SF_API size_t sf_row_order_workspace(int n_bound);
 /* Number of ints the row_order buffer of sf_row_order_by_mask must hold for n_bound rows. */
 SF_API int sf_row_order_size(int n_bound);
 
-/* row_order[0, *n_dev) = the output rows of a neighbour table sorted (stably) by their K-bit
- * neighbour mask (bit k set <=> nbr[k][row] >= 0); entries [*n_dev, n_bound) are unspecified.
- * row_order[n_bound, n_bound + ceil(*n_dev / 64)) = the tile schedule: the 64-row tiles of the
- * sorted rows by descending work (number of (16-row block, offset) products), which
- * sf_sparse_conv_f32_ordered deals to its persistent workgroups.  The buffer holds
- * sf_row_order_size(n_bound) ints.  The sort is a hand-written 3-pass radix sort bounded by the
- * device-side row count (no library call, no host synchronisation).
+/* Builds the PLAN of a rulebook for sf_sparse_conv_f32_ordered in row_order (T = ceil(n_bound/64)):
+ *   [0, n_bound)            the output rows sorted (stably) by their K-bit neighbour mask (bit k set
+ *                           <=> nbr[k][row] >= 0); entries [*n_dev, n_bound) are -1 or unspecified
+ *   [n_bound, +T)           the tile schedule: the 64-row tiles of the sorted rows by descending work
+ *                           (number of (16-row block, offset) products), dealt to the persistent
+ *                           workgroups of the convolution
+ *   + 32 T                  tile headers: [0] active offsets, [1..27] k | block mask << 8 ascending,
+ *                           [28] work, [29] mask of the active offsets
+ *   + 27 * 64 T             the neighbour table permuted into the sorted order, column per offset
+ * The buffer holds sf_row_order_size(n_bound) ints.  The sort is a hand-written 3-pass radix sort
+ * bounded by the device-side row count (no library call, no host synchronisation); six launches
+ * and one memset per rulebook.
  * No reference counterpart: the reference's rulebook has no row order of its own (pairs are
  * listed per offset, spconv_ops.h:55-59); this is the schedule sf_sparse_conv_f32_ordered runs
  * its tiles in, built once per rulebook and shared by every layer that uses it. */
@@ -300,9 +305,10 @@ SF_API int sf_row_order_by_mask(const int *nbr, int nbr_stride, int K, const int
 
 /* sf_sparse_conv_f32 (same reference interface: indice_conv_fp32 / indice_subm_conv,
  * spconv_ops.h:260-361, + the fused BN / residual / ReLU tail) with a different work
- * decomposition: tiles of 64 entries of row_order (a buffer written by sf_row_order_by_mask for
- * the same n_out_bound, tile schedule included; NULL = natural order), no pair compaction,
- * sums kept in the MFMA accumulators, (offset, 16-row block) products without a partner skipped.
+ * decomposition: tiles of 64 entries of row_order (the plan written by sf_row_order_by_mask for
+ * the same neighbour table and the same n_out_bound; required), no pair compaction, sums kept in
+ * the MFMA accumulators, (offset, 16-row block) products without a partner skipped.  The kernel
+ * reads the plan's permuted table; nbr / nbr_stride are only validated.
  * Results are fp32 FMA chains in the reference's order (centre offset first for SubM, then
  * offsets ascending), independent of row_order.  features_in is (n_in_bound, cin_padded) f32
  * with cin_padded in {16, 32, 64, 128}: n_in_bound rows must be addressable (the gather is bounds

@@ -29,6 +29,8 @@
 //     stores straight from the accumulators after the folded BN / residual / ReLU epilogue.
 // Per output element the FMA chain is: centre offset, then offsets ascending, channels ascending
 // -- fixed, no atomics, independent of the row order.
+#include <stdlib.h>
+
 #include "sf_common.h"
 
 namespace {
@@ -52,95 +54,108 @@ struct ATileF {
   __device__ static __forceinline__ int pos(int p, int c) { return c ^ ((p / R) & M); }
 };
 
-// ---- row order: stable LSD radix sort of (27-bit mask, row), 3 passes of 9 bits ------------------
+// ---- the plan of a rulebook: row order + tile headers + sorted neighbour table --------------------
+// Built once per rulebook (sf_row_order_by_mask), read by every layer that uses the rulebook:
+//   plan[0, n_bound)                 row_order: output rows by ascending 27-bit neighbour mask (stable)
+//   plan[n_bound, +T)                tile schedule: tiles by descending work (T = ceil(n_bound / 64))
+//   + T x 32 ints                    tile headers: [0] number of active offsets, [1..27] the active
+//                                    offsets ascending as k | (16-row block mask << 8), [28] work,
+//                                    [29] 27-bit mask of the active offsets
+//   + 27 x (64 T) ints               the neighbour table permuted into row_order (column per offset):
+//                                    a tile reads 256 contiguous bytes per offset
 // Hand-written (no library call on the path): every kernel is bounded by the DEVICE-side row count
 // (blocks past it exit at once), so a rulebook sized for its 8x geometric bound costs what its
-// real rows cost.
+// real rows cost.  Stable LSD radix sort, 3 passes of 9 bits, four launches: masks + first
+// histogram | scatter 1 (+ histogram 2) | scatter 2 (+ histogram 3) | scatter 3.  A scatter block
+// derives its bin offsets from the per-chunk histogram table itself (a few hundred KB in L2), and
+// counts the NEXT digit of every key into the chunk the key lands in, so no separate scan or
+// histogram launch is needed.
 constexpr int kSortChunk = 2048;   // keys per 256-thread block: 4 waves x 8 batches of 64
 constexpr int kSortBins = 512;     // 9-bit digits
-constexpr int kTileRows = 64;      // rows per tile of the ordered kernels (schedule granularity)
+constexpr int kTileRows = 64;      // rows per tile of the ordered kernels
+constexpr int kHdrInts = 32;
 
-__global__ void row_mask_kernel(const int *__restrict__ nbr, int nbr_stride, int K,
-                                const int *n_dev, int n_bound, unsigned *__restrict__ keys) {
-  const int n = load_n(n_dev, n_bound);
-  const int n_round = (n + kSortChunk - 1) / kSortChunk * kSortChunk;  // whole chunks are sorted
-  const int end = n_round < n_bound ? n_round : n_bound;
-  for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < end; o += gridDim.x * blockDim.x) {
-    unsigned m = 0xFFFFFFFFu;  // rows past the count sort behind every real row
-    if (o < n) {
-      m = 0;
-      for (int k = 0; k < K; ++k) m |= (unsigned)(nbr[(size_t)k * nbr_stride + o] >= 0) << k;
-    }
-    keys[o] = m;
-  }
-}
-
-// pass 1 of a digit: per-block histogram, hist[bin * nblk_bound + block]
 __global__ void __launch_bounds__(256)
-sort_hist_kernel(const unsigned *__restrict__ keys, const int *n_dev, int n_bound, int shift,
-                 int nblk_bound, int *__restrict__ hist) {
+mask_hist_kernel(const int *__restrict__ nbr, int nbr_stride, int K, const int *n_dev, int n_bound,
+                 unsigned *__restrict__ keys, int *__restrict__ hist) {
   __shared__ int s_h[kSortBins];
   const int n = load_n(n_dev, n_bound);
-  const int base = blockIdx.x * kSortChunk;
-  if (base >= n) return;
+  const int base = blockIdx.x * 256;             // eight blocks share a sort chunk
+  if (base >= (n + kSortChunk - 1) / kSortChunk * kSortChunk) return;
   for (int i = threadIdx.x; i < kSortBins; i += 256) s_h[i] = 0;
   __syncthreads();
-  for (int i = threadIdx.x; i < kSortChunk; i += 256) {
-    const int o = base + i;
-    const unsigned key = o < n_bound ? keys[o] : 0xFFFFFFFFu;
-    atomicAdd(&s_h[(key >> shift) & (kSortBins - 1)], 1);
+  const int o = base + threadIdx.x;
+  unsigned m = 0xFFFFFFFFu;  // rows past the count sort behind every real row
+  if (o < n) {
+    int v[kMaxK];
+#pragma unroll
+    for (int k = 0; k < kMaxK; ++k) v[k] = k < K ? nbr[(size_t)k * nbr_stride + o] : -1;
+    m = 0;
+#pragma unroll
+    for (int k = 0; k < kMaxK; ++k) m |= (unsigned)(v[k] >= 0) << k;
   }
+  if (o < n_bound) keys[o] = m;
+  atomicAdd(&s_h[m & (kSortBins - 1)], 1);
   __syncthreads();
-  for (int i = threadIdx.x; i < kSortBins; i += 256) hist[(size_t)i * nblk_bound + blockIdx.x] = s_h[i];
+  int *h = hist + (size_t)(base / kSortChunk) * kSortBins;
+  for (int i = threadIdx.x; i < kSortBins; i += 256)
+    if (s_h[i]) atomicAdd(&h[i], s_h[i]);
 }
 
-// pass 2: exclusive scan of the (bin-major, block-minor) histogram over the ACTIVE blocks, one
-// 1024-thread workgroup
-__global__ void __launch_bounds__(1024)
-sort_scan_kernel(const int *n_dev, int n_bound, int nblk_bound, int *__restrict__ hist) {
-  __shared__ int smem[17];
-  const int n = load_n(n_dev, n_bound);
-  const int nblk = (n + kSortChunk - 1) / kSortChunk;
-  const int total = nblk * kSortBins;
-  const int per = (total + 1023) / 1024;
-  const int lo = threadIdx.x * per, hi = (lo + per < total) ? lo + per : total;
-  int sum = 0;
-  for (int e = lo; e < hi; ++e) sum += hist[(size_t)(e / nblk) * nblk_bound + e % nblk];
-  int tot;
-  int run = sf_block_excl_scan(sum, smem, &tot);
-  for (int e = lo; e < hi; ++e) {
-    int *p = &hist[(size_t)(e / nblk) * nblk_bound + e % nblk];
-    const int v = *p;
-    *p = run;
-    run += v;
-  }
-}
-
-// pass 3: stable scatter.  A wave owns 512 consecutive keys of the block's chunk and places them
-// batch by batch (64 at a time, in order); lanes of one batch that share a digit are ranked by
-// lane (a match over the 9 digit bits).
+// One stable pass.  hist[chunk][bin] = keys of this pass's digit `bin` in `chunk`.  A wave owns 512
+// consecutive keys of the block's chunk and places them batch by batch (64 at a time, in order);
+// lanes of one batch that share a digit are ranked by lane (a match over the 9 digit bits).
 __global__ void __launch_bounds__(256)
 sort_scatter_kernel(const unsigned *__restrict__ keys, const int *__restrict__ rows,
-                    const int *n_dev, int n_bound, int shift, int nblk_bound,
-                    const int *__restrict__ hist, unsigned *__restrict__ keys_out,
-                    int *__restrict__ rows_out) {
+                    const int *n_dev, int n_bound, int shift, const int *__restrict__ hist,
+                    unsigned *__restrict__ keys_out, int *__restrict__ rows_out,
+                    int *__restrict__ hist_next) {
   __shared__ int s_h[4][kSortBins];
+  __shared__ int s_base[kSortBins];
+  __shared__ int smem[17];
   const int n = load_n(n_dev, n_bound);
   const int base = blockIdx.x * kSortChunk;
   if (base >= n) return;
+  const int nchunk = (n + kSortChunk - 1) / kSortChunk;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < 4 * kSortBins; i += 256) (&s_h[0][0])[i] = 0;
-  __syncthreads();
+  // keys first (their latency hides behind the histogram sums)
   unsigned key[8];
 #pragma unroll
   for (int b = 0; b < 8; ++b) {
     const int o = base + wave * 512 + b * 64 + lane;
     key[b] = o < n_bound ? keys[o] : 0xFFFFFFFFu;
-    atomicAdd(&s_h[wave][(key[b] >> shift) & (kSortBins - 1)], 1);
   }
+  // bins 2t and 2t+1: keys of the bin in all chunks, and in the chunks before this one
+  int tot[2] = {0, 0}, pre[2] = {0, 0};
+  {
+    const int2 *h2 = reinterpret_cast<const int2 *>(hist) + threadIdx.x;
+    for (int c0 = 0; c0 < nchunk; c0 += 16) {     // 16 independent loads per round trip
+      int2 v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int c = c0 + u < nchunk ? c0 + u : nchunk - 1;
+        v[u] = h2[(size_t)c * (kSortBins / 2)];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int live = c0 + u < nchunk ? 1 : 0, before = c0 + u < (int)blockIdx.x ? 1 : 0;
+        tot[0] += live * v[u].x;
+        tot[1] += live * v[u].y;
+        pre[0] += before * v[u].x;
+        pre[1] += before * v[u].y;
+      }
+    }
+  }
+  int all;
+  const int excl = sf_block_excl_scan(tot[0] + tot[1], smem, &all);  // (has the barrier s_h needs)
+  s_base[2 * threadIdx.x] = excl + pre[0];
+  s_base[2 * threadIdx.x + 1] = excl + tot[0] + pre[1];
+#pragma unroll
+  for (int b = 0; b < 8; ++b) atomicAdd(&s_h[wave][(key[b] >> shift) & (kSortBins - 1)], 1);
   __syncthreads();
   for (int i = threadIdx.x; i < kSortBins; i += 256) {
-    int run = hist[(size_t)i * nblk_bound + blockIdx.x];
+    int run = s_base[i];
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
       const int c = s_h[w][i];
@@ -167,29 +182,53 @@ sort_scatter_kernel(const unsigned *__restrict__ keys, const int *__restrict__ r
     if (rank == 0) *cursor = pos + __popcll(m);
     __builtin_amdgcn_wave_barrier();
     if (o < n_bound && pos < n_bound) {
-      keys_out[pos] = key[b];
+      if (keys_out) keys_out[pos] = key[b];
       rows_out[pos] = rows ? rows[o] : o;
+      if (hist_next)
+        atomicAdd(&hist_next[(size_t)(pos / kSortChunk) * kSortBins +
+                             ((key[b] >> (shift + 9)) & (kSortBins - 1))], 1);
     }
   }
 }
 
-// Work of every tile of kTileRows sorted rows = number of (16-row block, offset) products it
-// needs; one wave per tile.
+// One wave per tile of 64 sorted rows: permuted neighbour table, active offsets with their 16-row
+// block masks, work of the tile (number of (offset, block) products).
 __global__ void __launch_bounds__(256)
-tile_weight_kernel(const unsigned *__restrict__ keys_sorted, const int *n_dev, int n_bound,
-                   int *__restrict__ weight) {
+tile_plan_kernel(const int *__restrict__ nbr, int nbr_stride, int K, const int *n_dev, int n_bound,
+                 int *__restrict__ order, int *__restrict__ hdr, int *__restrict__ nbrs, int s_stride) {
   const int n = load_n(n_dev, n_bound);
   const int tiles = (n + kTileRows - 1) / kTileRows;
   const int lane = threadIdx.x & 63;
   for (int t = blockIdx.x * 4 + (threadIdx.x >> 6); t < tiles; t += gridDim.x * 4) {
     const int e = t * kTileRows + lane;
-    unsigned m = e < n ? (keys_sorted[e] & 0x7FFFFFFu) : 0u;
+    const int row = e < n ? order[e] : -1;
+    if (e >= n && e < n_bound) order[e] = -1;
+    int mybm = 0;
+    int vv[kMaxK];
 #pragma unroll
-    for (int d = 1; d < 16; d <<= 1) m |= (unsigned)__shfl_xor((int)m, d, 64);
-    int w = (lane & 15) == 0 ? __popc(m) : 0;
-    w += __shfl_xor(w, 16, 64);
-    w += __shfl_xor(w, 32, 64);
-    if (lane == 0) weight[t] = w;
+    for (int k = 0; k < kMaxK; ++k) vv[k] = (k < K && row >= 0) ? nbr[(size_t)k * nbr_stride + row] : -1;
+#pragma unroll
+    for (int k = 0; k < kMaxK; ++k) {
+      const int v = vv[k];
+      if (k < K) nbrs[(size_t)k * s_stride + e] = v;
+      const unsigned long long bal = __ballot(v >= 0);
+      int bm = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) bm |= (int)(((bal >> (16 * b)) & 0xFFFFull) != 0) << b;
+      if (lane == k) mybm = bm;
+    }
+    const unsigned long long act = __ballot(mybm != 0);
+    const int pos = __popcll(act & ((1ull << lane) - 1ull));
+    int *h = hdr + (size_t)t * kHdrInts;
+    if (mybm != 0) h[1 + pos] = lane | (mybm << 8);
+    int w = __popc(mybm);
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) w += __shfl_xor(w, d, 64);
+    if (lane == 0) {
+      h[0] = __popcll(act);
+      h[28] = w;
+      h[29] = (int)(unsigned)act;
+    }
   }
 }
 
@@ -197,14 +236,14 @@ tile_weight_kernel(const unsigned *__restrict__ keys_sorted, const int *n_dev, i
 // workgroup).  Dealt to the persistent workgroups in snake order it is a longest-processing-time
 // assignment: the heaviest tiles are spread first, the light ones level the tails.
 __global__ void __launch_bounds__(1024)
-tile_schedule_kernel(const int *__restrict__ weight, const int *n_dev, int n_bound,
+tile_schedule_kernel(const int *__restrict__ hdr, const int *n_dev, int n_bound,
                      int *__restrict__ sched) {
   __shared__ int s_cnt[128];
   const int n = load_n(n_dev, n_bound);
   const int tiles = (n + kTileRows - 1) / kTileRows;
   if (threadIdx.x < 128) s_cnt[threadIdx.x] = 0;
   __syncthreads();
-  for (int t = threadIdx.x; t < tiles; t += 1024) atomicAdd(&s_cnt[127 - weight[t]], 1);
+  for (int t = threadIdx.x; t < tiles; t += 1024) atomicAdd(&s_cnt[127 - hdr[(size_t)t * kHdrInts + 28]], 1);
   __syncthreads();
   if (threadIdx.x == 0) {
     int run = 0;
@@ -216,32 +255,48 @@ tile_schedule_kernel(const int *__restrict__ weight, const int *n_dev, int n_bou
   }
   __syncthreads();
   // equal weights keep no particular order (the schedule affects timing only, never results)
-  for (int t = threadIdx.x; t < tiles; t += 1024) sched[atomicAdd(&s_cnt[127 - weight[t]], 1)] = t;
+  for (int t = threadIdx.x; t < tiles; t += 1024)
+    sched[atomicAdd(&s_cnt[127 - hdr[(size_t)t * kHdrInts + 28]], 1)] = t;
 }
 
-template <int CIN, int COUT, int TM, int CG, int WAVES, int MINB>
-__global__ void __launch_bounds__(WAVES * 64, MINB)
-conv_f32_ordered_kernel(const float *__restrict__ feat, unsigned feat_bytes,
-                        const int *__restrict__ nbr, int nbr_stride, int K, int k_first,
-                        const int *__restrict__ order, const f32x4 *__restrict__ wp,
-                        const float *__restrict__ scale, const float *__restrict__ shift,
-                        const float *__restrict__ residual, int relu, float *__restrict__ out,
-                        const int *n_out_dev, int n_out_bound) {
-  constexpr int NT = WAVES * 64, T = CIN / 16, ROWB = CIN * 4, CH = CIN / 4;
-  constexpr int NB = COUT / 16, NBW = NB / CG, RG = WAVES / CG, MBT = TM / 16, MBW = MBT / RG;
-  constexpr int ITEMS = TM * CH, GI = (ITEMS + NT - 1) / NT;
-  static_assert(TM % 16 == 0 && TM <= 64 && NB % CG == 0 && WAVES % CG == 0 && MBT % RG == 0 &&
-                    CIN % 16 == 0, "tile shape");
+struct PlanView {
+  const int *order, *sched, *hdr, *nbrs;
+  int s_stride;
+};
 
-  // dynamic LDS (the 128-channel tile passes the 64 KiB static limit):
-  // rows [2][TM*CH] x 16 B | neighbour columns [27][TM] | tile rows [TM] | block masks | list | count
+__host__ __device__ inline int plan_tiles(int n_bound) { return (n_bound + kTileRows - 1) / kTileRows; }
+
+// ---- the convolution ---------------------------------------------------------------------------
+// A persistent workgroup walks its tiles (snake deal of the schedule) as ONE stream of phases --
+// a phase = one active offset of one tile -- so that the loads of the next tile's first offsets
+// are in flight while the current tile still multiplies: per phase q the workgroup
+//   (1) issues the gathers of phase q+2 (raw buffer loads; a row without partner is an out-of-range
+//       offset: zeros, no memory access, no branch), whose row indices it loaded one phase earlier,
+//   (2) loads the row indices of phase q+3 from the sorted neighbour table (256 contiguous bytes),
+//   (3) loads the filter fragments of phase q+1,
+//   (4) multiplies phase q from LDS (the 16-row blocks that have a partner under this offset),
+//   (5) parks the rows of phase q+1 in the other LDS buffer;  one barrier.
+// Tiles are padded to three phases so that the look-ahead crosses at most one tile boundary; tile
+// headers travel through a ring of three LDS slots, loaded two tiles ahead.
+template <int CIN, int COUT, int CG, int WAVES, int MINB>
+__global__ void __launch_bounds__(WAVES * 64, MINB)
+conv_f32_ordered_kernel(const float *__restrict__ feat, unsigned feat_bytes, PlanView pv, int K,
+                        int k_first, const f32x4 *__restrict__ wp, const float *__restrict__ scale,
+                        const float *__restrict__ shift, const float *__restrict__ residual, int relu,
+                        float *__restrict__ out, const int *n_out_dev, int n_out_bound,
+                        unsigned long long *__restrict__ prof) {
+  constexpr int TM = kTileRows, NT = WAVES * 64, T = CIN / 16, ROWB = CIN * 4, CH = CIN / 4;
+  constexpr int NB = COUT / 16, NBW = NB / CG, RG = WAVES / CG, MBT = TM / 16, MBW = MBT / RG;
+  constexpr int ITEMS = TM * CH, GI = ITEMS / NT;
+  constexpr int kRun = 128;   // tiles per pipeline run
+  constexpr int kLook = 3;    // look-ahead in phases = least phases per tile (shorter tiles are padded)
+  static_assert(NB % CG == 0 && WAVES % CG == 0 && MBT % RG == 0 && CIN % 16 == 0 && ITEMS % NT == 0,
+                "tile shape");
+
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  u32x4(*s_a)[TM * CH] = reinterpret_cast<u32x4(*)[TM * CH]>(lds_raw);
-  int *s_nbr = reinterpret_cast<int *>(lds_raw + (size_t)2 * TM * CH * 16);
-  int *s_row = s_nbr + kMaxK * TM;
-  int *s_kmask = s_row + TM;
-  int *s_list = s_kmask + 32;
-  int &s_nact = s_list[32];
+  constexpr int BUFB = TM * ROWB;                                             // bytes of one row buffer
+  int *s_hdr = reinterpret_cast<int *>(lds_raw + (size_t)2 * BUFB);           // [3][32]
+  int *s_tiles = s_hdr + 3 * kHdrInts;                                        // [kRun]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -252,88 +307,130 @@ conv_f32_ordered_kernel(const float *__restrict__ feat, unsigned feat_bytes,
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(feat), 0, feat_bytes, 0x00020000);
   const int kf = (k_first >= 0 && k_first < K) ? k_first : -1;
   const int tiles = (n_out + TM - 1) / TM;
-  // tiles in the schedule's order (descending work), dealt to the persistent workgroups in snake
-  // order: round j gives workgroup b entry j*G + b (even j) or j*G + G-1-b (odd j)
-  const int *__restrict__ sched = order ? order + n_out_bound : nullptr;
-  const int G = gridDim.x;
+  const int G = gridDim.x, b = blockIdx.x;
+  // snake deal: round i gives this workgroup schedule entry i*G + b (even i) or i*G + G-1-b (odd i)
+  const int full = tiles / G, rem = tiles - full * G;
+  const int my_n = full + ((((full & 1) ? G - 1 - b : b) < rem) ? 1 : 0);
 
-  for (int j = 0; j * G < tiles; ++j) {
-    const int slot = j * G + ((j & 1) ? G - 1 - (int)blockIdx.x : (int)blockIdx.x);
-    if (slot >= tiles) continue;
-    const int tile = sched ? sched[slot] : slot;
-    const int row0 = tile * TM;
-    // ---- setup ------------------------------------------------------------------------
-    if (tid < TM) {
-      const int e = row0 + tid;
-      s_row[tid] = e < n_out ? (order ? order[e] : e) : -1;
+  f32x4 acc[MBW][NBW];
+  u32x4 greg[2][GI];
+  f32x4 bf[2][NBW][T];
+  int ireg[GI], orow[MBW];
+#pragma unroll
+  for (int m = 0; m < GI; ++m) {
+    greg[0][m] = greg[1][m] = (u32x4){0u, 0u, 0u, 0u};
+    ireg[m] = -1;
+  }
+#pragma unroll
+  for (int mb = 0; mb < MBW; ++mb) {
+    orow[mb] = -1;
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) acc[mb][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  unsigned long long pt[6] = {0, 0, 0, 0, 0, 0};
+  const unsigned long long tk0 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
+  for (int run0 = 0; run0 < my_n; run0 += kRun) {
+    const int cnt = (my_n - run0 < kRun) ? my_n - run0 : kRun;
+    __syncthreads();   // the previous run is drained
+    if (tid < cnt) {
+      const int i = run0 + tid;
+      s_tiles[tid] = pv.sched[(size_t)i * G + ((i & 1) ? G - 1 - b : b)];
     }
     __syncthreads();
-    for (int k = wave; k < K; k += WAVES) {
-      const int o = lane < TM ? s_row[lane] : -1;
-      const int v = o >= 0 ? nbr[(size_t)k * nbr_stride + o] : -1;
-      if (lane < TM) s_nbr[k * TM + lane] = v;
-      const unsigned long long bal = __ballot(v >= 0);
-      int bm = 0;
-#pragma unroll
-      for (int b = 0; b < MBT; ++b) bm |= (int)(((bal >> (16 * b)) & 0xFFFFull) != 0) << b;
-      if (lane == 0) s_kmask[k] = bm;
-    }
+    if (tid < 2 * kHdrInts && (tid >> 5) < cnt)
+      s_hdr[tid] = pv.hdr[(size_t)s_tiles[tid >> 5] * kHdrInts + (tid & 31)];
     __syncthreads();
-    if (wave == 0) {
-      const int bm = lane < K ? s_kmask[lane] : 0;
-      const unsigned long long act = __ballot(bm != 0);
-      const int below = __popcll(act & ((1ull << lane) - 1ull));
-      const bool cf = kf >= 0 && ((act >> kf) & 1ull);  // the centre offset goes first
-      int pos = below;
-      if (cf) pos = lane == kf ? 0 : (lane < kf ? below + 1 : below);
-      if (bm != 0) s_list[pos] = lane | (bm << 8);
-      if (lane == 0) s_nact = __popcll(act);
-    }
-    __syncthreads();
-    const int nact = s_nact;
 
-    f32x4 acc[MBW][NBW];
-#pragma unroll
-    for (int mb = 0; mb < MBW; ++mb)
-#pragma unroll
-      for (int i = 0; i < NBW; ++i) acc[mb][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    u32x4 greg[2][GI];
-    f32x4 bf[2][NBW][T];
-#pragma unroll
-    for (int m = 0; m < GI; ++m) greg[0][m] = greg[1][m] = (u32x4){0u, 0u, 0u, 0u};
-
-    // one phase; PAR = parity of kk: LDS buffer / filter set of phase kk, register set that
-    // receives the rows of phase kk+2
-    auto phase = [&](int kk, auto PAR) {
-      constexpr int par = decltype(PAR)::value;
-      // (1) filters of phase kk+1 first, then rows of phase kk+2
-      {
-        int i1 = kk + 1 < 0 ? 0 : kk + 1;
-        i1 = i1 < nact ? i1 : nact - 1;
-        const int k1 = s_list[i1] & 31;
-#pragma unroll
-        for (int i = 0; i < NBW; ++i)
-#pragma unroll
-          for (int t = 0; t < T; ++t)
-            bf[par ^ 1][i][t] = wp[(((size_t)k1 * NB + (cg * NBW + i)) * T + t) * 64 + lane];
-        const int v2 = kk + 2;
-        const int k2 = s_list[v2 < nact ? v2 : nact - 1] & 31;
-#pragma unroll
-        for (int m = 0; m < GI; ++m) {
-          const int it = tid + m * NT, p = it / CH, c = it % CH;
-          int src = s_nbr[k2 * TM + (p < TM ? p : 0)];
-          src = (v2 < nact && it < ITEMS) ? src : -1;  // -1: out of range, zeros, no fetch
-          greg[par][m] = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)src * ROWB + c * 16, 0, 0);
+    // phase descriptors: tile, info = k | block mask << 5 | flags << 9
+    //   flags: 1 multiply, 2 first phase of its tile, 4 last phase of its tile, 8 second phase
+    // The generator's tile header sits in a register (lane i holds entry i), so a descriptor costs a
+    // few scalar instructions and two v_readlane, no LDS round trip on the phase's critical path.
+    int gj = 0, ga = 0;        // generator: tile (within the run) and phase of the NEXT descriptor
+    int hcur = s_hdr[lane & 31], g_tile = __builtin_amdgcn_readfirstlane(s_tiles[0]);
+    auto next_desc = [&](int &d_tile, int &d_info) {
+      d_tile = 0;
+      d_info = 0;
+      if (gj < cnt) {
+        const int nact = __builtin_amdgcn_readlane(hcur, 0), np = nact > kLook ? nact : kLook;
+        int li = ga;           // list index: the centre offset first, then ascending
+        if (kf >= 0) {
+          const unsigned am = (unsigned)__builtin_amdgcn_readlane(hcur, 29);
+          if ((am >> kf) & 1u) {
+            const int pc = __popc(am & ((1u << kf) - 1u));
+            li = ga == 0 ? pc : (ga <= pc ? ga - 1 : ga);
+          }
+        }
+        const int e = ga < nact ? __builtin_amdgcn_readlane(hcur, 1 + (li < 27 ? li : 0)) : 0;
+        d_tile = g_tile;
+        d_info = (e & 31) | (((e >> 8) & 15) << 5) |
+                 (((ga < nact ? 1 : 0) | (ga == 0 ? 2 : 0) | (ga == np - 1 ? 4 : 0) | (ga == 1 ? 8 : 0) | 16) << 9);
+        if (++ga == np) {
+          ++gj;
+          ga = 0;
+          if (gj < cnt) {
+            hcur = s_hdr[(gj % 3) * kHdrInts + (lane & 31)];
+            g_tile = __builtin_amdgcn_readfirstlane(s_tiles[gj]);
+          }
         }
       }
-      // (2) this phase: the row blocks that have a partner under this offset.  In mask order
+    };
+    int tA = 0, iA = 0, tB = 0, iB = 0, tC = 0, iC = 0, tD = 0, iD = 0;
+    int cj = -1;               // tile (within the run) of the current phase
+    int hreg = 0;
+
+    auto phase = [&](auto PAR) {
+      constexpr int par = decltype(PAR)::value;
+      const unsigned long long ts0 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
+      tA = tB; iA = iB; tB = tC; iB = iC; tC = tD; iC = iD;
+      next_desc(tD, iD);
+      // load order matters (the counter of outstanding loads retires in order): row indices of
+      // phase q+3 first, then the filters of phase q+1, then the gathers of phase q+2 -- so the
+      // wait for the filters (next phase's MFMAs) and for the indices (next phase's gathers) never
+      // retires the gathers early; they are only waited for where they are parked, at the end of
+      // the NEXT phase (a gather that misses the L2 takes longer than one phase).
+      {
+        int inew[GI];
+        const int *ip = pv.nbrs + (size_t)(iD & 31) * pv.s_stride + (size_t)tD * TM;
+#pragma unroll
+        for (int m = 0; m < GI; ++m) inew[m] = ip[(tid + m * NT) / CH];
+        {
+          const int k1 = iB & 31;
+#pragma unroll
+          for (int i = 0; i < NBW; ++i)
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+              bf[par ^ 1][i][t] = wp[(((size_t)k1 * NB + (cg * NBW + i)) * T + t) * 64 + lane];
+        }
+        const bool live = (iC >> 9) & 1;
+#pragma unroll
+        for (int m = 0; m < GI; ++m) {
+          const int c = (tid + m * NT) % CH;
+          const int src = live ? ireg[m] : -1;   // -1: out of range, zeros, no fetch
+          greg[par][m] = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)src * ROWB + c * 16, 0, 0);
+        }
+#pragma unroll
+        for (int m = 0; m < GI; ++m) ireg[m] = inew[m];
+      }
+      const int fl = iA >> 9;
+      const unsigned long long ts1 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
+      if (fl & 2) {            // first phase of a tile: fresh sums, its output rows, header of tile +2
+        ++cj;
+#pragma unroll
+        for (int mb = 0; mb < MBW; ++mb) {
+          const int e = tA * TM + (rg * MBW + mb) * 16 + ln;
+          orow[mb] = e < n_out ? pv.order[e] : -1;
+#pragma unroll
+          for (int i = 0; i < NBW; ++i) acc[mb][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (tid < kHdrInts && cj + 2 < cnt) hreg = pv.hdr[(size_t)s_tiles[cj + 2] * kHdrInts + tid];
+      }
+      // (3) this phase: the row blocks that have a partner under this offset.  In mask order
       //     nearly every phase has all of the wave's blocks active: that case is a straight line
-      //     (a branch per block and MFMA measured a wait in front of every MFMA); the rest takes
-      //     the blocks one by one.
-      if (kk >= 0 && kk < nact) {
-        const int bmw =
-            (__builtin_amdgcn_readfirstlane(s_list[kk]) >> (8 + rg * MBW)) & ((1 << MBW) - 1);
-        const char *sa = reinterpret_cast<const char *>(s_a[par]);
+      //     (a branch per block and MFMA measured a wait in front of every MFMA)
+      if (fl & 1) {
+        const int bmw = (iA >> (5 + rg * MBW)) & ((1 << MBW) - 1);
+        const char *sa = reinterpret_cast<const char *>(lds_raw) + par * BUFB;
         auto a_at = [&](int mb, int t) {
           const int p = (rg * MBW + mb) * 16 + ln;
           return *reinterpret_cast<const f32x4 *>(sa + p * ROWB + 16 * ATileF<CIN>::pos(p, 4 * t + g));
@@ -359,9 +456,10 @@ conv_f32_ordered_kernel(const float *__restrict__ feat, unsigned feat_bytes,
                                                                    acc[mb][i], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
           }
-        } else if (bmw != 0) {
+        } else {
+          if (bmw != 0) {
 #pragma unroll
-          for (int mb = 0; mb < MBW; ++mb)
+            for (int mb = 0; mb < MBW; ++mb)
             if ((bmw >> mb) & 1) {  // uniform
 #pragma unroll
               for (int t = 0; t < T; ++t) {
@@ -374,57 +472,84 @@ conv_f32_ordered_kernel(const float *__restrict__ feat, unsigned feat_bytes,
                                                                      acc[mb][i], 0, 0, 0);
               }
             }
+          }
         }
       }
-      // (3) park the rows of phase kk+1 (issued one phase ago) in the other LDS buffer
+      const unsigned long long ts2 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
+      if (fl & 4) {
+        // ---- end of a tile: folded BN, residual, ReLU, straight from the accumulators; every
+        //      load first, so the tile end costs one round trip ----------------------------------
+        f32x4 sc[NBW], sh[NBW], rsd[MBW][NBW];
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) {
+          const int c = (cg * NBW + i) * 16 + 4 * g;
+          sc[i] = scale ? *reinterpret_cast<const f32x4 *>(scale + c) : (f32x4){1.f, 1.f, 1.f, 1.f};
+          sh[i] = scale ? *reinterpret_cast<const f32x4 *>(shift + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int mb = 0; mb < MBW; ++mb) {
+            const int row = orow[mb] < 0 ? 0 : orow[mb];
+            rsd[mb][i] = residual ? *reinterpret_cast<const f32x4 *>(residual + (size_t)row * COUT + c)
+                                  : (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
+        }
+#pragma unroll
+        for (int mb = 0; mb < MBW; ++mb) {
+          const int row = orow[mb];
+#pragma unroll
+          for (int i = 0; i < NBW; ++i) {
+            const int c = (cg * NBW + i) * 16 + 4 * g;
+            f32x4 v = acc[mb][i];
+            if (scale) v = v * sc[i] + sh[i];
+            if (residual) v += rsd[mb][i];
+            if (relu) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.0f ? v[j] : 0.0f;
+            }
+            if (row >= 0) *reinterpret_cast<f32x4 *>(out + (size_t)row * COUT + c) = v;
+          }
+        }
+      }
+      if ((fl & 8) && tid < kHdrInts && cj + 2 < cnt) s_hdr[((cj + 2) % 3) * kHdrInts + tid] = hreg;
+      // park the rows of phase q+1 (issued one phase ago) in the other LDS buffer
       {
-        char *sn = reinterpret_cast<char *>(s_a[par ^ 1]);
+        char *sn = reinterpret_cast<char *>(lds_raw) + (par ^ 1) * BUFB;
 #pragma unroll
         for (int m = 0; m < GI; ++m) {
           const int it = tid + m * NT, p = it / CH, c = it % CH;
-          if (ITEMS % NT == 0 || it < ITEMS)
-            *reinterpret_cast<u32x4 *>(sn + p * ROWB + 16 * ATileF<CIN>::pos(p, c)) = greg[par ^ 1][m];
+          *reinterpret_cast<u32x4 *>(sn + p * ROWB + 16 * ATileF<CIN>::pos(p, c)) = greg[par ^ 1][m];
         }
       }
+      const unsigned long long ts3 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
       __syncthreads();
+      if (prof) {
+        const unsigned long long ts4 = __builtin_amdgcn_s_memtime();
+        pt[0] += ts1 - ts0;   // park + load issue
+        pt[1] += ts2 - ts1;   // first-phase work + MFMA section
+        pt[2] += ts3 - ts2;   // epilogue
+        pt[3] += ts4 - ts3;   // barrier
+        pt[4] += 1;           // phases
+        pt[5] += (fl & 1);    // multiplying phases
+      }
     };
-    if (nact > 0)
-      for (int kk = -2; kk < nact; kk += 2) {
-        phase(kk, std::integral_constant<int, 0>{});
-        phase(kk + 1, std::integral_constant<int, 1>{});
-      }
-
-    // ---- epilogue: folded BN, residual, ReLU, straight from the accumulators ---------------
-#pragma unroll
-    for (int mb = 0; mb < MBW; ++mb) {
-      const int row = s_row[(rg * MBW + mb) * 16 + ln];
-      if (row < 0) continue;
-#pragma unroll
-      for (int i = 0; i < NBW; ++i) {
-        const int c = (cg * NBW + i) * 16 + 4 * g;
-        f32x4 v = acc[mb][i];
-        if (scale) {
-          v = v * *reinterpret_cast<const f32x4 *>(scale + c) +
-              *reinterpret_cast<const f32x4 *>(shift + c);
-        }
-        if (residual) v += *reinterpret_cast<const f32x4 *>(residual + (size_t)row * COUT + c);
-        if (relu) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.0f ? v[j] : 0.0f;
-        }
-        *reinterpret_cast<f32x4 *>(out + (size_t)row * COUT + c) = v;
-      }
-    }
-    __syncthreads();  // s_row / lists are rewritten by the next tile
+    do {
+      phase(std::integral_constant<int, 0>{});
+      phase(std::integral_constant<int, 1>{});
+    } while (((iA | iB | iC | iD) >> 13) & 1);
+  }
+  if (prof && (tid & 63) == 0) {
+    for (int i = 0; i < 6; ++i) atomicAdd(&prof[i], pt[i]);
+    atomicAdd(&prof[6], (unsigned long long)__builtin_amdgcn_s_memtime() - tk0);
+    atomicAdd(&prof[7], 1ull);
   }
 }
+
+unsigned long long *g_ord_prof = nullptr;   // diagnostic only, see sf_debug_ordered_profile
 
 struct OrdArgs {
   const float *feat;
   unsigned feat_bytes;
-  const int *nbr;
-  int nbr_stride, K, k_first;
-  const int *order;
+  int K, k_first;
+  const int *plan;
   const float *wpk, *scale, *shift, *residual;
   int relu;
   float *out;
@@ -433,20 +558,27 @@ struct OrdArgs {
   hipStream_t st;
 };
 
-template <int CIN, int COUT, int TM, int CG, int WAVES, int MINB>
+PlanView plan_view(const int *plan, int n_bound) {
+  const int tiles = plan_tiles(n_bound);
+  PlanView v;
+  v.order = plan;
+  v.sched = plan + n_bound;
+  v.hdr = v.sched + tiles;
+  v.nbrs = v.hdr + (size_t)tiles * kHdrInts;
+  v.s_stride = tiles * kTileRows;
+  return v;
+}
+
+template <int CIN, int COUT, int CG, int WAVES, int MINB>
 int launch_ordered(const OrdArgs &a) {
-  constexpr size_t lds = (size_t)2 * TM * (CIN / 4) * 16 + (size_t)(kMaxK * TM + TM + 32 + 33) * 4;
+  constexpr size_t lds = (size_t)2 * kTileRows * (CIN / 4) * 16 + (size_t)(3 * kHdrInts + 128) * 4;
   static_assert(lds <= 160 * 1024, "tile does not fit LDS");
-  auto kern = conv_f32_ordered_kernel<CIN, COUT, TM, CG, WAVES, MINB>;
-  static bool attr_set = false;
-  if (lds > 48 * 1024 && !attr_set) {
-    SF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
-  static_assert(TM == kTileRows, "the tile schedule is built for kTileRows-row tiles");
+  auto kern = conv_f32_ordered_kernel<CIN, COUT, CG, WAVES, MINB>;
   static int slots = 0;          // resident workgroups on the device
   if (slots == 0) {
+    if (lds > 48 * 1024)
+      SF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int dev = 0, cus = 256, per_cu = 1;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
@@ -456,12 +588,12 @@ int launch_ordered(const OrdArgs &a) {
       per_cu = 1;
     slots = cus * per_cu;
   }
-  const int tiles = sf_div_up(a.n_out_bound, TM);
+  const int tiles = plan_tiles(a.n_out_bound);
   const int grid = tiles < slots ? tiles : slots;
-  hipLaunchKernelGGL(kern, dim3(grid),
-                     dim3(WAVES * 64), lds, a.st, a.feat, a.feat_bytes, a.nbr, a.nbr_stride, a.K,
-                     a.k_first, a.order, reinterpret_cast<const f32x4 *>(a.wpk), a.scale, a.shift,
-                     a.residual, a.relu, a.out, a.n_out_dev, a.n_out_bound);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, a.st, a.feat, a.feat_bytes,
+                     plan_view(a.plan, a.n_out_bound), a.K, a.k_first,
+                     reinterpret_cast<const f32x4 *>(a.wpk), a.scale, a.shift, a.residual, a.relu,
+                     a.out, a.n_out_dev, a.n_out_bound, g_ord_prof);
   SF_CHECK_LAUNCH();
   return SF_OK;
 }
@@ -471,35 +603,34 @@ int launch_ordered(const OrdArgs &a) {
 template <int CIN>
 int dispatch_ordered(int cout, const OrdArgs &a) {
   switch (cout) {
-    case 16: return launch_ordered<CIN, 16, 64, 1, 4, 2>(a);
-    case 32: return launch_ordered<CIN, 32, 64, 2, 4, 2>(a);
-    case 64: return launch_ordered<CIN, 64, 64, 4, 4, (CIN <= 64 ? 3 : 2)>(a);
+    case 16: return launch_ordered<CIN, 16, 1, 4, 2>(a);
+    case 32: return launch_ordered<CIN, 32, 2, 4, 2>(a);
+    case 64: return launch_ordered<CIN, 64, 4, 4, 2>(a);   // (3 per CU spills: 146 -> 163 us at 64 -> 64)
     case 128:
-      if constexpr (CIN >= 128) return launch_ordered<CIN, 128, 64, 8, 8, 1>(a);
-      else return launch_ordered<CIN, 128, 64, 4, 4, 2>(a);
+      if constexpr (CIN >= 128) return launch_ordered<CIN, 128, 8, 8, 1>(a);
+      else return launch_ordered<CIN, 128, 4, 4, 2>(a);
   }
   sf_set_error("unsupported cout=%d (16, 32, 64 or 128)", cout);
   return SF_ERR_BAD_ARG;
 }
 
-}  // namespace
-
-namespace {
 size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 int sort_blocks(int n_bound) { return sf_div_up(n_bound > 0 ? n_bound : 1, kSortChunk); }
+
 }  // namespace
 
 extern "C" size_t sf_row_order_workspace(int n_bound) {
   if (n_bound < 1) n_bound = 1;
   const size_t arr = align_up((size_t)n_bound * 4);
-  const size_t tiles = (size_t)sf_div_up(n_bound, kTileRows);
-  // keys x2, rows x2, per-block histograms, tile weights
-  return 4 * arr + align_up((size_t)sort_blocks(n_bound) * kSortBins * 4) + align_up(tiles * 4);
+  // keys x2, rows x2, three per-chunk histogram tables
+  return 4 * arr + 3 * align_up((size_t)sort_blocks(n_bound) * kSortBins * 4);
 }
 
 extern "C" int sf_row_order_size(int n_bound) {
   if (n_bound < 1) n_bound = 1;
-  return n_bound + sf_div_up(n_bound, kTileRows);
+  const long long tiles = plan_tiles(n_bound);
+  const long long ints = (long long)n_bound + tiles + tiles * kHdrInts + 27ll * tiles * kTileRows;
+  return ints < 0x7FFFFFFFll ? (int)ints : -1;   // -1: more than 2^31 ints (n_bound beyond ~75 M rows)
 }
 
 extern "C" int sf_row_order_by_mask(const int *nbr, int nbr_stride, int K, const int *n_dev,
@@ -517,36 +648,35 @@ extern "C" int sf_row_order_by_mask(const int *nbr, int nbr_stride, int K, const
   }
   const size_t arr = align_up((size_t)n_bound * 4);
   const int nblk = sort_blocks(n_bound);
+  const size_t tab = align_up((size_t)nblk * kSortBins * 4);
   char *ws = (char *)workspace;
   unsigned *keys0 = (unsigned *)ws, *keys1 = (unsigned *)(ws + arr);
   int *rows0 = (int *)(ws + 2 * arr), *rows1 = (int *)(ws + 3 * arr);
-  int *hist = (int *)(ws + 4 * arr);
-  int *weight = (int *)(ws + 4 * arr + align_up((size_t)nblk * kSortBins * 4));
-  int *sched = row_order + n_bound;
-  hipLaunchKernelGGL(row_mask_kernel, dim3(sf_grid(n_bound, 256)), dim3(256), 0, st, nbr, nbr_stride,
-                     K, n_dev, n_bound, keys0);
+  int *hist0 = (int *)(ws + 4 * arr), *hist1 = (int *)(ws + 4 * arr + tab),
+      *hist2 = (int *)(ws + 4 * arr + 2 * tab);
+  const PlanView pv = plan_view(row_order, n_bound);
+  SF_CHECK_HIP(hipMemsetAsync(hist0, 0, 3 * tab, st));
+  hipLaunchKernelGGL(mask_hist_kernel, dim3(nblk * (kSortChunk / 256)), dim3(256), 0, st, nbr, nbr_stride, K, n_dev,
+                     n_bound, keys0, hist0);
   SF_CHECK_LAUNCH();
   // three stable passes over the 27 mask bits; the last one lands in row_order
-  const unsigned *kin[3] = {keys0, keys1, keys0};
-  unsigned *kout[3] = {keys1, keys0, keys1};
-  const int *rin[3] = {nullptr, rows1, rows0};   // pass 0 starts from the identity
-  int *rout[3] = {rows1, rows0, row_order};
-  for (int p = 0; p < 3; ++p) {
-    hipLaunchKernelGGL(sort_hist_kernel, dim3(nblk), dim3(256), 0, st, kin[p], n_dev, n_bound, 9 * p,
-                       nblk, hist);
-    SF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(1024), 0, st, n_dev, n_bound, nblk, hist);
-    SF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(sort_scatter_kernel, dim3(nblk), dim3(256), 0, st, kin[p], rin[p], n_dev,
-                       n_bound, 9 * p, nblk, (const int *)hist, kout[p], rout[p]);
-    SF_CHECK_LAUNCH();
-  }
-  const int tiles = sf_div_up(n_bound, kTileRows);
-  hipLaunchKernelGGL(tile_weight_kernel, dim3(sf_grid(tiles, 4)), dim3(256), 0, st,
-                     (const unsigned *)keys1, n_dev, n_bound, weight);
+  hipLaunchKernelGGL(sort_scatter_kernel, dim3(nblk), dim3(256), 0, st, (const unsigned *)keys0,
+                     (const int *)nullptr, n_dev, n_bound, 0, (const int *)hist0, keys1, rows1, hist1);
   SF_CHECK_LAUNCH();
-  hipLaunchKernelGGL(tile_schedule_kernel, dim3(1), dim3(1024), 0, st, (const int *)weight, n_dev,
-                     n_bound, sched);
+  hipLaunchKernelGGL(sort_scatter_kernel, dim3(nblk), dim3(256), 0, st, (const unsigned *)keys1,
+                     (const int *)rows1, n_dev, n_bound, 9, (const int *)hist1, keys0, rows0, hist2);
+  SF_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sort_scatter_kernel, dim3(nblk), dim3(256), 0, st, (const unsigned *)keys0,
+                     (const int *)rows0, n_dev, n_bound, 18, (const int *)hist2, (unsigned *)nullptr,
+                     row_order, (int *)nullptr);
+  SF_CHECK_LAUNCH();
+  const int tiles = plan_tiles(n_bound);
+  hipLaunchKernelGGL(tile_plan_kernel, dim3(sf_grid(tiles, 4)), dim3(256), 0, st, nbr, nbr_stride, K,
+                     n_dev, n_bound, row_order, const_cast<int *>(pv.hdr),
+                     const_cast<int *>(pv.nbrs), pv.s_stride);
+  SF_CHECK_LAUNCH();
+  hipLaunchKernelGGL(tile_schedule_kernel, dim3(1), dim3(1024), 0, st, pv.hdr, n_dev, n_bound,
+                     const_cast<int *>(pv.sched));
   SF_CHECK_LAUNCH();
   return SF_OK;
 }
@@ -563,6 +693,7 @@ extern "C" int sf_sparse_conv_f32_ordered(const float *features_in, int n_in_bou
   SF_CHECK_ARG((scale == nullptr) == (shift == nullptr), "scale and shift go together");
   if (n_out_bound == 0) return SF_OK;
   SF_CHECK_ARG(features_in && nbr && w_packed && out, "NULL tensor pointer");
+  SF_CHECK_ARG(row_order, "row_order is NULL: the kernel runs on the plan sf_row_order_by_mask wrote");
   SF_CHECK_ARG(((uintptr_t)features_in & 15) == 0 && ((uintptr_t)out & 15) == 0 &&
                    ((uintptr_t)w_packed & 15) == 0 && ((uintptr_t)residual & 15) == 0 &&
                    ((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0,
@@ -570,8 +701,8 @@ extern "C" int sf_sparse_conv_f32_ordered(const float *features_in, int n_in_bou
   const long long bytes = (long long)n_in_bound * cin_padded * 4;
   SF_CHECK_ARG(n_in_bound >= 1 && bytes < (1ll << 32) - 4096,
                "the input feature table (%d rows) must stay below 4 GiB", n_in_bound);
-  OrdArgs a{features_in, (unsigned)bytes, nbr, nbr_stride, K, k_first, row_order, w_packed, scale,
-            shift, residual, relu, out, n_out_dev, n_out_bound, (hipStream_t)stream};
+  OrdArgs a{features_in, (unsigned)bytes, K, k_first, row_order, w_packed, scale, shift, residual,
+            relu, out, n_out_dev, n_out_bound, (hipStream_t)stream};
   switch (cin_padded) {
     case 16: return dispatch_ordered<16>(cout, a);
     case 32: return dispatch_ordered<32>(cout, a);
@@ -580,4 +711,11 @@ extern "C" int sf_sparse_conv_f32_ordered(const float *features_in, int n_in_bou
   }
   sf_set_error("unsupported cin_padded=%d for the ordered kernel (16, 32, 64 or 128)", cin_padded);
   return SF_ERR_BAD_ARG;
+}
+
+// Diagnostic hook (not part of the documented ABI): a device buffer of 8 uint64 that every ordered
+// conv launch accumulates per-wave cycle stamps into (issue, multiply, epilogue, barrier, phases,
+// multiplying phases, cycles in kernel, waves); NULL = off.
+extern "C" __attribute__((visibility("default"))) void sf_debug_ordered_profile(void *dev_buf8) {
+  g_ord_prof = (unsigned long long *)dev_buf8;
 }

@@ -142,7 +142,7 @@ class Rulebook:
         return self._pairs
 
 
-_ORDERED_DEFAULT = ''      # filled in from measurements (tools/ab_ordered.py, bench.py)
+_ORDERED_DEFAULT = '64x64,128x128'
 
 
 def use_ordered(cin_padded, cout):

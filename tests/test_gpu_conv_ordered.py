@@ -52,14 +52,25 @@ def test_row_order_is_a_mask_sorted_permutation(dev, oracle, subm, ks, st, pd):
     blocks = np.bitwise_or.reduce(pad.reshape(-1, 16), axis=1)
     work = np.array([bin(int(b)).count('1') for b in blocks]).reshape(tiles, 4).sum(1)
     assert np.all(np.diff(work[sched]) <= 0)
+    # tile headers (active offsets ascending with their 16-row block masks) and the permuted table
+    hdr = order[n + tiles:n + tiles + 32 * tiles].reshape(tiles, 32)
+    tab = order[n + 33 * tiles:n + 33 * tiles + 27 * 64 * tiles].reshape(27, tiles * 64)
+    want = np.full((27, tiles * 64), -1, np.int32)
+    want[:rb.K, :n] = nbr[:, order[:n]]
+    assert np.array_equal(tab[:rb.K], want[:rb.K])
+    for t in range(tiles):
+        bm = [(want[k, t * 64:(t + 1) * 64].reshape(4, 16) >= 0).any(1) for k in range(rb.K)]
+        act = [(k | (int(sum(int(v) << i for i, v in enumerate(bm[k]))) << 8)) for k in range(rb.K)
+               if bm[k].any()]
+        assert hdr[t, 0] == len(act) and list(hdr[t, 1:1 + len(act)]) == act
+        assert hdr[t, 28] == work[t]
 
 
 @pytest.mark.parametrize('cin,cout,subm,ks,st,pd', [
     (16, 16, True, 3, 1, 1), (16, 32, False, 3, 2, 1), (32, 32, True, 3, 1, 1),
     (32, 64, False, 3, 2, 1), (64, 64, True, 3, 1, 1), (64, 128, False, 3, 2, (0, 1, 1)),
     (128, 128, True, 3, 1, 1), (128, 128, False, (3, 1, 1), (2, 1, 1), 0), (128, 64, True, 3, 1, 1)])
-@pytest.mark.parametrize('ordered', [True, False])
-def test_ordered_conv_matches_oracle(dev, oracle, cin, cout, subm, ks, st, pd, ordered):
+def test_ordered_conv_matches_oracle(dev, oracle, cin, cout, subm, ks, st, pd):
     rng = np.random.default_rng(cin + cout)
     coors = _coords(oracle, 50 + cin, 5000)
     n_in = coors.shape[0]
@@ -82,11 +93,11 @@ def test_ordered_conv_matches_oracle(dev, oracle, cin, cout, subm, ks, st, pd, o
     d_feats, d_w = to_dev(feats, dev), spconv.pack_filters(to_dev(w, dev))
     d_scale, d_shift = to_dev(scale, dev), to_dev(shift, dev)
     d_res = to_dev(res, dev) if res is not None else None
-    order = _row_order(rb, dev) if ordered else None
+    order = _row_order(rb, dev)
     out = torch.full((n_out, cout), np.nan, dtype=torch.float32, device=dev)
     _lib.check(L.sf_sparse_conv_f32_ordered(
         d_feats.data_ptr(), n_in, cin, rb.nbr.data_ptr(), rb.nbr.shape[1], rb.K, rb.k_first,
-        order.data_ptr() if ordered else None, d_w.data_ptr(), cout, d_scale.data_ptr(),
+        order.data_ptr(), d_w.data_ptr(), cout, d_scale.data_ptr(),
         d_shift.data_ptr(), _lib.ptr(d_res), 1, out.data_ptr(), None, n_out, _lib.stream(dev)))
     torch.cuda.synchronize()
     assert_close(out.cpu().numpy(), expect)
@@ -125,10 +136,13 @@ def test_bad_arguments(dev):
     L = _lib.lib()
     x = torch.zeros(64, 16, device=dev)
     nbr = torch.full((27, 64), -1, dtype=torch.int32, device=dev)
-    assert L.sf_sparse_conv_f32_ordered(x.data_ptr(), 64, 8, nbr.data_ptr(), 64, 27, 13, None,
+    assert L.sf_sparse_conv_f32_ordered(x.data_ptr(), 64, 8, nbr.data_ptr(), 64, 27, 13, nbr.data_ptr(),
                                         x.data_ptr(), 16, None, None, None, 0, x.data_ptr(), None, 64,
                                         None) < 0
     assert b'cin_padded' in L.sf_last_error()
+    assert L.sf_sparse_conv_f32_ordered(x.data_ptr(), 64, 16, nbr.data_ptr(), 64, 27, 13, None,
+                                        x.data_ptr(), 16, None, None, None, 0, x.data_ptr(), None, 64,
+                                        None) < 0       # the plan of sf_row_order_by_mask is required
     assert L.sf_row_order_by_mask(nbr.data_ptr(), 64, 27, None, 64, x.data_ptr(), x.data_ptr(), 16,
                                   None) < 0
     assert b'workspace' in L.sf_last_error()
