@@ -142,7 +142,7 @@ class Rulebook:
         return self._pairs
 
 
-_ORDERED_DEFAULT = '64x64,128x128'
+_ORDERED_DEFAULT = '64x64,128x128'   # measured: tools/ab_layers.sh, bench.py
 
 
 def use_ordered(cin_padded, cout):

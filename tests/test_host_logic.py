@@ -78,9 +78,11 @@ def test_conv_output_size_rule():
 
 
 def test_ordered_kernel_selection(monkeypatch):
-    """SF_CONV_ORDERED: which fp32 layer shapes run on the mask-ordered kernel (default: none)."""
+    """SF_CONV_ORDERED: which fp32 layer shapes run on the mask-ordered kernel (default: the 64- and
+    128-channel SubM shapes, where it measured faster end to end)."""
     monkeypatch.delenv('SF_CONV_ORDERED', raising=False)
-    assert not spconv.use_ordered(64, 64)
+    assert spconv.use_ordered(64, 64) and spconv.use_ordered(128, 128)
+    assert not spconv.use_ordered(32, 32) and not spconv.use_ordered(64, 128)
     monkeypatch.setenv('SF_CONV_ORDERED', '32x32,64x64')
     assert spconv.use_ordered(64, 64) and spconv.use_ordered(32, 32)
     assert not spconv.use_ordered(128, 128) and not spconv.use_ordered(8, 16)
