@@ -294,8 +294,8 @@ SF_API int sf_row_order_size(int n_bound);
  *                           [28] work, [29] mask of the active offsets
  *   + 27 * 64 T             the neighbour table permuted into the sorted order, column per offset
  * The buffer holds sf_row_order_size(n_bound) ints.  The sort is a hand-written 3-pass radix sort
- * bounded by the device-side row count (no library call, no host synchronisation); six launches
- * and one memset per rulebook.
+ * bounded by the device-side row count (no library call, no host synchronisation); seven short
+ * launches per rulebook.
  * No reference counterpart: the reference's rulebook has no row order of its own (pairs are
  * listed per offset, spconv_ops.h:55-59); this is the schedule sf_sparse_conv_f32_ordered runs
  * its tiles in, built once per rulebook and shared by every layer that uses it. */

@@ -75,6 +75,18 @@ constexpr int kSortBins = 512;     // 9-bit digits
 constexpr int kTileRows = 64;      // rows per tile of the ordered kernels
 constexpr int kHdrInts = 32;
 
+// zeroes the histogram rows of the chunks in use (the tables are sized for the bound)
+__global__ void __launch_bounds__(256)
+hist_zero_kernel(const int *n_dev, int n_bound, int *__restrict__ hist, size_t table_ints) {
+  const int n = load_n(n_dev, n_bound);
+  const int used = (n + kSortChunk - 1) / kSortChunk * kSortBins;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < used; i += gridDim.x * 256) {
+    hist[i] = 0;
+    hist[table_ints + i] = 0;
+    hist[2 * table_ints + i] = 0;
+  }
+}
+
 __global__ void __launch_bounds__(256)
 mask_hist_kernel(const int *__restrict__ nbr, int nbr_stride, int K, const int *n_dev, int n_bound,
                  unsigned *__restrict__ keys, int *__restrict__ hist) {
@@ -184,9 +196,22 @@ sort_scatter_kernel(const unsigned *__restrict__ keys, const int *__restrict__ r
     if (o < n_bound && pos < n_bound) {
       if (keys_out) keys_out[pos] = key[b];
       rows_out[pos] = rows ? rows[o] : o;
-      if (hist_next)
-        atomicAdd(&hist_next[(size_t)(pos / kSortChunk) * kSortBins +
-                             ((key[b] >> (shift + 9)) & (kSortBins - 1))], 1);
+    }
+    if (hist_next) {
+      // next digit of the key, counted into the chunk the key lands in.  Lanes of the batch that
+      // hit the same counter (the rule: equal keys land side by side) add once, through a leader;
+      // one atomic per key made the popular masks serialise at the L2.
+      const bool ok = o < n_bound && pos < n_bound;
+      const unsigned cell = ok ? (unsigned)(pos / kSortChunk) * kSortBins +
+                                     ((key[b] >> (shift + 9)) & (kSortBins - 1))
+                               : 0xFFFFFFFFu;
+      unsigned long long mm = ~0ull;
+#pragma unroll
+      for (int bit = 0; bit < 32; ++bit) {
+        const unsigned long long bal = __ballot((cell >> bit) & 1u);
+        mm &= ((cell >> bit) & 1u) ? bal : ~bal;
+      }
+      if (ok && (mm & lt) == 0) atomicAdd(&hist_next[cell], (int)__popcll(mm));
     }
   }
 }
@@ -655,7 +680,9 @@ extern "C" int sf_row_order_by_mask(const int *nbr, int nbr_stride, int K, const
   int *hist0 = (int *)(ws + 4 * arr), *hist1 = (int *)(ws + 4 * arr + tab),
       *hist2 = (int *)(ws + 4 * arr + 2 * tab);
   const PlanView pv = plan_view(row_order, n_bound);
-  SF_CHECK_HIP(hipMemsetAsync(hist0, 0, 3 * tab, st));
+  hipLaunchKernelGGL(hist_zero_kernel, dim3(nblk < 128 ? nblk : 128), dim3(256), 0, st, n_dev, n_bound,
+                     hist0, tab / 4);
+  SF_CHECK_LAUNCH();
   hipLaunchKernelGGL(mask_hist_kernel, dim3(nblk * (kSortChunk / 256)), dim3(256), 0, st, nbr, nbr_stride, K, n_dev,
                      n_bound, keys0, hist0);
   SF_CHECK_LAUNCH();

@@ -185,7 +185,7 @@ class LidarBackbone:
             rb['stride'] = nb
         # row order by neighbour mask for the rulebooks whose fp32 layers run on the ordered kernel
         for lay in self.layers:
-            lay.ordered = (not lay.bf16) and spconv.use_ordered(L.sf_conv_padded_cin(lay.cin), lay.cout)
+            lay.ordered = (not lay.bf16) and spconv.use_ordered(L.sf_conv_padded_cin(lay.cin), lay.cout, lay.rb['subm'])
             if lay.ordered and 'order' not in lay.rb:
                 nb_rows = self.sets[lay.rb['dst']]['bound']
                 lay.rb['order'] = i32(L.sf_row_order_size(nb_rows))

@@ -145,12 +145,17 @@ class Rulebook:
 _ORDERED_DEFAULT = '64x64,128x128'   # measured: tools/ab_layers.sh, bench.py
 
 
-def use_ordered(cin_padded, cout):
+def use_ordered(cin_padded, cout, subm=True):
     """Whether an fp32 layer of this shape runs on the mask-ordered kernel
     (sf_sparse_conv_f32_ordered) instead of the pair-compacting / direct ones.  SF_CONV_ORDERED
-    overrides: 'all', 'none' or a comma list of CINxCOUT shapes."""
+    overrides: 'all', 'none' or a comma list of CINxCOUT shapes.  By default only SubM layers
+    qualify: their rulebook (and so the plan the kernel needs) is shared by the four convolutions
+    of a stage, a strided rulebook is used once and its sort would cost more than it saves."""
     import os
-    sel = os.environ.get('SF_CONV_ORDERED', _ORDERED_DEFAULT).strip().lower()
+    sel = os.environ.get('SF_CONV_ORDERED')
+    if sel is None:
+        sel = _ORDERED_DEFAULT if subm else ''
+    sel = sel.strip().lower()
     if cin_padded < 16 or sel in ('', 'none', '0'):
         return False
     if sel in ('all', '1'):
@@ -425,7 +430,7 @@ def sparse_conv(features, packed_filters, cin, cout, rulebook, scale=None, shift
         if residual.shape != out.shape:
             raise RuntimeError('residual shape mismatch')
         residual = residual.contiguous()
-    if use_ordered(cp, cout) and n_out > 0:   # same selection as LidarBackbone: identical results
+    if use_ordered(cp, cout, rulebook.subm) and n_out > 0:   # same selection as LidarBackbone: identical results
         _lib.check(L.sf_sparse_conv_f32_ordered(
             _lib.ptr(x), x.shape[0], cp, rulebook.nbr.data_ptr(), rulebook.nbr.shape[1], rulebook.K,
             rulebook.k_first, rulebook.row_order().data_ptr(), _lib.ptr(packed_filters), cout,

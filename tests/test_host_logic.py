@@ -83,6 +83,7 @@ def test_ordered_kernel_selection(monkeypatch):
     monkeypatch.delenv('SF_CONV_ORDERED', raising=False)
     assert spconv.use_ordered(64, 64) and spconv.use_ordered(128, 128)
     assert not spconv.use_ordered(32, 32) and not spconv.use_ordered(64, 128)
+    assert not spconv.use_ordered(128, 128, subm=False)      # a strided rulebook is used once
     monkeypatch.setenv('SF_CONV_ORDERED', '32x32,64x64')
     assert spconv.use_ordered(64, 64) and spconv.use_ordered(32, 32)
     assert not spconv.use_ordered(128, 128) and not spconv.use_ordered(8, 16)
