@@ -627,35 +627,41 @@ class SparseSequential(SparseModule):
     applies plain nn.Modules to `.features`.  On top of that contract, a
     conv -> BatchNorm1d(eval) [-> ReLU] run is executed as ONE fused kernel."""
 
-    def __init__(self, *args, **kwargs):
+    def __init__(self, *layers, **named_layers):
+        """Accepts what the reference container accepts (modules.py:55-123): positional modules
+        (registered as '0', '1', ...), ONE ordered mapping name -> module, and/or keyword
+        modules; a keyword that repeats an existing name is an error."""
         super().__init__()
-        if len(args) == 1 and isinstance(args[0], OrderedDict):
-            for key, module in args[0].items():
-                self.add_module(key, module)
+        if len(layers) == 1 and isinstance(layers[0], OrderedDict):
+            entries = list(layers[0].items())
         else:
-            for idx, module in enumerate(args):
-                self.add_module(str(idx), module)
-        for name, module in kwargs.items():
-            if name in self._modules:
-                raise ValueError('name exists.')
-            self.add_module(name, module)
+            entries = [(str(pos), layer) for pos, layer in enumerate(layers)]
+        for name, layer in entries + list(named_layers.items()):
+            self._register_unique(name, layer)
 
-    def __getitem__(self, idx):
-        if not (-len(self) <= idx < len(self)):
-            raise IndexError('index {} is out of range'.format(idx))
-        if idx < 0:
-            idx += len(self)
-        return list(self._modules.values())[idx]
+    def _register_unique(self, name, layer):
+        if name in self._modules:
+            raise ValueError(f'SparseSequential already holds a layer called {name!r}')
+        self.add_module(name, layer)
 
     def __len__(self):
         return len(self._modules)
 
+    def __getitem__(self, position):
+        """Layer at `position` in registration order; negative positions count from the end."""
+        count = len(self)
+        if isinstance(position, slice):
+            raise TypeError('SparseSequential supports integer positions only')
+        resolved = position + count if position < 0 else position
+        if not 0 <= resolved < count:
+            raise IndexError(f'position {position} outside a SparseSequential of {count} layers')
+        for i, layer in enumerate(self._modules.values()):
+            if i == resolved:
+                return layer
+
     def add(self, module, name=None):
-        if name is None:
-            name = str(len(self._modules))
-            if name in self._modules:
-                raise KeyError('name exists')
-        self.add_module(name, module)
+        """Append a layer; without a name it takes the next position number."""
+        self._register_unique(str(len(self)) if name is None else name, module)
 
     def forward(self, input, out_dtype=None):
         """out_dtype: dtype of the features a fused conv -> BN [-> ReLU] run that ENDS the sequence

@@ -1,5 +1,6 @@
 """Host-side logic that needs no GPU: module tree / state-dict keys, weight-layout handling,
 registry entry points, BN folding, LidarBackbone planning."""
+import pytest
 import numpy as np
 import torch
 
@@ -129,3 +130,26 @@ def test_vfe_decorated_channels():
     assert decorated_channels(5, 1 | 2 | 8) == 11          # HardVFE: cluster + voxel centre
     assert decorated_channels(4, 1 | 2 | 16 | 32 | 8) == 9  # PillarFeatureNet: +3 +2
     assert decorated_channels(4, 1 | 2 | 4 | 16 | 8) == 10  # ... + distance
+
+
+def test_sparse_sequential_container():
+    """The container contract of modules.py:55-123: positional / ordered-dict / keyword layers,
+    integer indexing (negative from the end), add(), duplicate names rejected."""
+    import torch.nn as nn
+    from collections import OrderedDict
+    seq = spconv.SparseSequential(nn.ReLU(), nn.Identity(), tail=nn.ReLU())
+    assert len(seq) == 3 and isinstance(seq[1], nn.Identity) and seq[-1] is seq[2]
+    assert list(seq._modules) == ['0', '1', 'tail']
+    seq.add(nn.Identity())
+    seq.add(nn.ReLU(), 'named')
+    assert list(seq._modules) == ['0', '1', 'tail', '3', 'named'] and len(seq) == 5
+    od = spconv.SparseSequential(OrderedDict(a=nn.ReLU(), b=nn.Identity()))
+    assert isinstance(od[0], nn.ReLU) and isinstance(od[-1], nn.Identity)
+    with pytest.raises(IndexError):
+        seq[5]
+    with pytest.raises(IndexError):
+        seq[-6]
+    with pytest.raises(ValueError):
+        spconv.SparseSequential(nn.ReLU(), **{'0': nn.ReLU()})
+    with pytest.raises(ValueError):
+        seq.add(nn.ReLU(), 'tail')
