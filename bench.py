@@ -112,11 +112,12 @@ def time_layers(bb, pts, vf, iters=5, busy=None):
     conv_out of the last stage are one run of five)."""
     import sparsefusion_amd._lib as _lib
     L = _lib.lib()
-    keys = [(lay.cin, lay.cout, bool(lay.bf16)) for lay in bb.layers]
+    keys = [(lay.cin, lay.cout, bool(lay.bf16), lay.rb['K'], lay.rb['subm']) for lay in bb.layers]
     nl = len(keys)
     first = [i == 0 or keys[i] != keys[i - 1] for i in range(nl)]
     last = [i == nl - 1 or keys[i] != keys[i + 1] for i in range(nl)]
     evs, state = [], {'i': 0}
+    names = [None] * nl
 
     class Shim:
         def __getattr__(self, name):
@@ -131,6 +132,7 @@ def time_layers(bb, pts, vf, iters=5, busy=None):
                 e0.record()
                 evs.append([i, i, e0, None])
             rc = real(*a)
+            names[i] = L.sf_last_conv_kernel().decode()
             if last[i]:
                 e1 = torch.cuda.Event(enable_timing=True)
                 e1.record()
@@ -159,64 +161,125 @@ def time_layers(bb, pts, vf, iters=5, busy=None):
                 acc[a:b + 1] += ea.elapsed_time(eb) / (b - a + 1)
     finally:
         bb.L = old
-    return acc / iters  # ms per layer (run-averaged)
+    return acc / iters, names  # ms per layer (run-averaged), kernel launched per layer
 
 
-def measured_traffic(cin, cout, bf16=False):
-    """HBM-side bytes per launch of the conv instantiation, from the committed PMC passes
-    (profiles/r01_pmc_hbm_traffic.json: tools/pmc_traffic.sh, FETCH_SIZE doubled as the gfx950
-    note in MI355X_MICROARCH.md prescribes, WRITE_SIZE as read).  Counters cannot be collected
-    inside this process; None when the file has no such kernel."""
-    import re
-    path = os.path.join(ROOT, 'profiles',
-                        'r01_pmc_hbm_traffic_bf16.json' if bf16 else 'r01_pmc_hbm_traffic.json')
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
-        table = json.load(f)
-    pat = re.compile((r'conv_bf16_(tile|direct)_kernel<%d, %d,' if bf16 else
-                      r'(sparse_conv_f32(_wide|_direct)?|conv_f32_ordered)_kernel<%d, %d,') % (cin, cout))
-    hits = [v for k, v in table.items() if pat.match(k)]
-    if not hits:
-        return None
-    n = sum(v['launches'] for v in hits)
-    return round(sum(v['traffic_bytes'] * v['launches'] for v in hits) / n, 1)
+def frame_digest(bb):
+    """(rulebook sha256, BEV sha256) of the batch `bb` ran last.  The rulebook digest covers, for
+    every rulebook of the encoder, the output coordinates and the neighbour table in the CPU
+    reference's row order (first-touch order: the form the parity tests pin against the oracle),
+    so it is the same on every GPU that ran the same frame; so is the BEV map (fixed summation
+    order per output element)."""
+    import hashlib
+    torch.cuda.synchronize()
+    c = bb.counts.tolist()
+    h = hashlib.sha256()
+    h.update(np.asarray(c[:-1], np.int64).tobytes())
+    for rb in bb.rulebooks:
+        n = c[rb['dst']]
+        h.update(bb.sets[rb['dst']]['indices'][:n].cpu().numpy().tobytes())
+        h.update(rb['nbr'][:, :n].contiguous().cpu().numpy().tobytes())
+    return h.hexdigest(), sharding.checksum(bb.bev.cpu().numpy())
 
 
-def cpu_baseline(cfg, ecfg, sd, points, workload):
-    """The oracle (port of the reference's CPU path) on one frame; returns frames/s."""
+def measured_traffic(kernel, bf16=False):
+    """HBM-side bytes per launch of `kernel` (the exact name rocprofv3 prints) from the committed
+    PMC passes of this command (tools/pmc_traffic.sh: FETCH_SIZE / WRITE_SIZE collected and corrected
+    as MI355X_MICROARCH.md prescribes).  Counters cannot be collected inside this process, so the
+    number is read from the newest profiles/rNN_pmc_hbm_traffic*.json that lists the kernel; returns
+    (bytes, 'profiles/<file>') or (None, None)."""
+    import glob
+    pat = 'r*_pmc_hbm_traffic_bf16.json' if bf16 else 'r*_pmc_hbm_traffic.json'
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', pat)), reverse=True):
+        with open(path) as f:
+            table = json.load(f)
+        hits = [v for k, v in table.items() if k.replace(' ', '').startswith(kernel.replace(' ', ''))]
+        if hits:
+            n = sum(v['launches'] for v in hits)
+            return (round(sum(v['traffic_bytes'] * v['launches'] for v in hits) / n, 1),
+                    'profiles/' + os.path.basename(path))
+    return None, None
+
+
+def cpu_baseline(cfg, ecfg, sd, points, workload, repeats=5):
+    """The oracle (port of the reference's CPU path) on one frame: one warm-up pass, then the
+    median of `repeats` passes at the box's thread count, the per-stage split of SURVEY 8d
+    (voxelize / VFE / rulebook / gather / GEMM / scatter-add / BN+ReLU / dense), and ONE pass on a
+    single thread (`threads_1`, the reference's CPU ops are single-threaded apart from torch.mm).
+    Returns (dict, bev of the last pass)."""
     from oracle import oracle as O
     O.lib()
     vl = cfg['pts_voxel_layer']
     mv = vl['max_voxels'][1] if isinstance(vl['max_voxels'], (tuple, list)) else vl['max_voxels']
-    t0 = time.perf_counter()
-    v, c, n = O.hard_voxelize(points, vl['voxel_size'], vl['point_cloud_range'],
-                              vl['max_num_points'], mv)
-    t1 = time.perf_counter()
-    if workload == 'nusc':
-        feats = O.vfe_mean(v, n, ecfg['in_channels'])
-    else:
-        vcfg = cfg['pts_voxel_encoder']
-        layers = []
-        for i in range(len(vcfg['feat_channels'])):
-            p = f'vfe.vfe_layers.{i}'
-            layers.append((sd[f'{p}.linear.weight'],
-                           {k: sd[f'{p}.norm.{k}'] for k in ('weight', 'bias', 'running_mean',
-                                                              'running_var')}))
-        feats = O.hard_vfe(v, n, O.batch_coors([c]), layers, vcfg['voxel_size'],
-                           vcfg['point_cloud_range'], vcfg['norm_cfg']['eps'],
-                           vcfg['with_cluster_center'], vcfg['with_voxel_center'])
-    sd = {k: v for k, v in sd.items() if not k.startswith('vfe.')}
+    enc_sd = {k: v for k, v in sd.items() if not k.startswith('vfe.')}
     wcfg = {k: ecfg[k] for k in ('base_channels', 'output_channels', 'encoder_channels',
                                  'encoder_paddings', 'block_type') if k in ecfg}
-    bev = O.sparse_encoder_forward(sd, feats, O.batch_coors([c]), 1, ecfg['sparse_shape'],
-                                   ecfg['in_channels'], **wcfg)
-    t2 = time.perf_counter()
-    return dict(value=round(1.0 / (t2 - t0), 4), unit='frames/s', cores=int(O.lib().sfo_num_threads()),
-                kind='port',
-                sample=f'1 full frame (frame 0, {points.shape[0]} points -> {c.shape[0]} voxels): '
-                       f'voxelize {t1 - t0:.2f} s + VFE/SparseEncoder {t2 - t1:.2f} s; OpenMP on the '
-                       f'GEMM rows only, rest single-threaded as in the reference'), bev
+    stage = {}
+
+    def timed(name, fn):
+        def wrapped(*a, **kw):
+            t = time.perf_counter()
+            r = fn(*a, **kw)
+            stage[name] = stage.get(name, 0.0) + time.perf_counter() - t
+            return r
+        return wrapped
+
+    def one_pass():
+        stage.clear()
+        O.conv_stage_times(reset=True)
+        saved = (O.get_indice_pairs, O.bn_act, O.dense_bev, O.indice_conv)
+        O.get_indice_pairs = timed('rulebook', saved[0])
+        O.bn_act = timed('bn_relu', saved[1])
+        O.dense_bev = timed('dense', saved[2])
+        O.indice_conv = timed('conv', saved[3])
+        try:
+            t0 = time.perf_counter()
+            v, c, n = O.hard_voxelize(points, vl['voxel_size'], vl['point_cloud_range'],
+                                      vl['max_num_points'], mv)
+            t1 = time.perf_counter()
+            if workload == 'nusc':
+                feats = O.vfe_mean(v, n, ecfg['in_channels'])
+            else:
+                vcfg = cfg['pts_voxel_encoder']
+                layers = []
+                for i in range(len(vcfg['feat_channels'])):
+                    p = f'vfe.vfe_layers.{i}'
+                    layers.append((sd[f'{p}.linear.weight'],
+                                   {k: sd[f'{p}.norm.{k}'] for k in ('weight', 'bias', 'running_mean',
+                                                                      'running_var')}))
+                feats = O.hard_vfe(v, n, O.batch_coors([c]), layers, vcfg['voxel_size'],
+                                   vcfg['point_cloud_range'], vcfg['norm_cfg']['eps'],
+                                   vcfg['with_cluster_center'], vcfg['with_voxel_center'])
+            t2 = time.perf_counter()
+            bev = O.sparse_encoder_forward(enc_sd, feats, O.batch_coors([c]), 1, ecfg['sparse_shape'],
+                                           ecfg['in_channels'], **wcfg)
+            t3 = time.perf_counter()
+        finally:
+            O.get_indice_pairs, O.bn_act, O.dense_bev, O.indice_conv = saved
+        g, m, sc = O.conv_stage_times(reset=True)
+        split = dict(voxelize=t1 - t0, vfe=t2 - t1, rulebook=stage.get('rulebook', 0.0), gather=g,
+                     gemm=m, scatter_add=sc, bn_relu=stage.get('bn_relu', 0.0),
+                     dense=stage.get('dense', 0.0))
+        split['other'] = (t3 - t0) - sum(split.values())
+        return t3 - t0, split, bev, c.shape[0]
+
+    threads = int(O.lib().sfo_num_threads())
+    one_pass()                                             # warm-up: page in, allocator, clocks
+    runs = [one_pass() for _ in range(repeats)]
+    runs.sort(key=lambda r: r[0])
+    secs, split, bev, nvox = runs[len(runs) // 2]
+    O.lib().sfo_set_num_threads(1)
+    try:
+        secs1 = one_pass()[0]
+    finally:
+        O.lib().sfo_set_num_threads(threads)
+    return dict(value=round(1.0 / secs, 4), unit='frames/s', cores=threads, kind='port',
+                threads_1=round(1.0 / secs1, 4), passes=repeats,
+                spread=[round(1.0 / runs[-1][0], 4), round(1.0 / runs[0][0], 4)],
+                stages_ms={k: round(v * 1e3, 1) for k, v in split.items()},
+                sample=f'1 full frame (frame 0, {points.shape[0]} points -> {nvox} voxels): 1 warm-up + '
+                       f'median of {repeats} passes at {threads} threads, then 1 pass at 1 thread; '
+                       f'OpenMP on the GEMM rows only, rest single-threaded as in the reference'), bev
 
 
 def main():
@@ -242,6 +305,7 @@ def main():
     ap.add_argument('--no-overlap', action='store_true',
                     help='coordinate phase on the main stream instead of a forked one')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-passes', type=int, default=5, help='timed passes of the CPU baseline')
     ap.add_argument('--detail', default='', help='write per-layer timing/roofline JSON here')
     args = ap.parse_args()
 
@@ -335,10 +399,10 @@ def main():
                 for _ in range(nb):
                     steps[0][1][fi]()
 
-            ms, work, counts = None, None, None
+            ms, work, counts, knames = None, None, None, None
             for fi, fr in enumerate(frames):
                 busy = None if args.no_graph else (lambda: keep_busy(fi))
-                ms_f = time_layers(bb, fr, vf, iters=3, busy=busy)
+                ms_f, knames = time_layers(bb, fr, vf, iters=3, busy=busy)
                 bb.enqueue(fr, vf)
                 torch.cuda.synchronize()
                 work_f, counts_f = layer_work(bb)
@@ -359,9 +423,13 @@ def main():
             if res['overflow']:
                 raise SystemExit('overflow flag set: a bound was exceeded')
             groups = {}
-            for w, t in zip(work, ms):
-                gkey = (w['cin'], w['cout'], w['bf16'])
-                g_ = groups.setdefault(gkey, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+            for w, t, kn in zip(work, ms, knames):
+                gkey = (w['cin'], w['cout'], w['bf16'], w['K'], w['subm'])
+                g_ = groups.setdefault(gkey, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0,
+                                                  kernels=[]))
+                w['kernel'] = kn
+                if kn not in g_['kernels']:
+                    g_['kernels'].append(kn)
                 g_['ms'] += t
                 g_['flops'] += w['flops']
                 g_['bytes'] += w['bytes']
@@ -382,14 +450,12 @@ def main():
                 ach = by / avg_s / 1e9
                 roofline = dict(bound='hbm', achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit='GB/s',
                                 frac=round(ach / PEAK_HBM_GBS, 4), traffic=None)
-            if dom[2]:
-                roofline['kernel'] = f'conv_bf16_kernel<{max(dom[0], 16)},{dom[1]}>'
-                roofline['traffic'] = measured_traffic(max(dom[0], 16), dom[1], True)
-            else:
-                ordered = any(getattr(l, 'ordered', False) and (l.cin, l.cout) == dom[:2] for l in bb.layers)
-                roofline['kernel'] = (f'conv_f32_ordered_kernel<{dom[0]},{dom[1]}>' if ordered else
-                                      f'sparse_conv_f32_kernel<{dom[0] if dom[0] > 8 else 8},{dom[1]}>')
-                roofline['traffic'] = measured_traffic(dom[0] if dom[0] > 8 else 8, dom[1])
+            # the kernel of the group's heaviest layer, named exactly as rocprofv3 prints it
+            heavy = max((w for w in work if (w['cin'], w['cout'], w['bf16'], w['K'], w['subm']) == dom),
+                        key=lambda w: w['ms'])
+            roofline['kernel'] = heavy['kernel']
+            roofline['kernels_in_group'] = gd['kernels']
+            roofline['traffic'], roofline['traffic_source'] = measured_traffic(heavy['kernel'], dom[2])
             roofline['launches_per_frame'] = gd['launches']
             roofline['avg_launch_us'] = round(avg_s * 1e6, 2)
             roofline['algorithmic_flops_per_launch'] = fl
@@ -397,9 +463,32 @@ def main():
             tot_fl, tot_by = sum(w['flops'] for w in work), sum(w['bytes'] for w in work)
             detail = dict(counts=counts[:-1], layers=work, conv_ms_per_frame=float(ms.sum()),
                           frame_flops=tot_fl, frame_bytes=tot_by,
-                          groups={f'{k[0]}x{k[1]}' + ('b' if k[2] else ''): v
+                          groups={f'{k[0]}x{k[1]}' + ('b' if k[2] else '') +
+                                  ('' if k[3] == 27 else f'k{k[3]}') + ('' if k[4] else 's'): v
                                   for k, v in groups.items()},
                           workspace_bytes=bb.memory_bytes())
+
+        # ---- what the job computed, checked across ranks (outside the timed region) -------------
+        # every batch of every rank must be present in the gathered table, and a batch recomputed
+        # on ANOTHER rank (rank 1 redoes rank 0's first batch) must give the same rulebooks and map
+        local = {}
+        for fi, fr in enumerate(frames):
+            bb.enqueue(fr, vf)
+            local[tuple(ids[fi * B:(fi + 1) * B])] = frame_digest(bb)
+        merged = sharding.gather_results(local)
+        recheck = {}
+        if world > 1 and rank == 1:
+            ids0 = sharding.frames_for_rank(0, world, world * args.frames * B)[:B]
+            if max(gen(i).shape[0] for i in ids0) <= max_pts:
+                bb.enqueue([torch.from_numpy(gen(i)).to(dev) for i in ids0], vf)
+                recheck[('recheck',) + tuple(ids0)] = frame_digest(bb)
+        recheck = sharding.gather_results(recheck)
+        expected = []
+        for r in range(world):
+            ids_r = sharding.frames_for_rank(r, world, world * args.frames * B)
+            expected += [tuple(ids_r[f * B:(f + 1) * B]) for f in range(args.frames)]
+        verified = sharding.verify_frames(merged, expected,
+                                          [(k[1:], v) for k, v in recheck.items()])
 
     ms_per_step = elapsed / args.steps * 1e3
     value = world * args.steps * B / elapsed
@@ -422,12 +511,15 @@ def main():
                        'bev_backbone': 'SECOND + SECONDFPN (fp32) on the BEV map' if args.second else None,
                        'hip_graph': not args.no_graph, 'frames_in_flight': args.streams, 'sharding': 'frames by rank, no collective'},
             'roofline': roofline,
+            'verified': {'batches_checked': verified, 'rechecked_on_another_rank': len(recheck),
+                         'frame0_rulebook_sha256': merged[expected[0]][0][:16],
+                         'frame0_bev_sha256': merged[expected[0]][1][:16]},
         }
         if detail:
             line['frame_algorithmic_gflop'] = round(detail['frame_flops'] / 1e9, 2)
             line['frame_algorithmic_gbyte'] = round(detail['frame_bytes'] / 1e9, 3)
         if world == 1 and not args.no_cpu_baseline:
-            cb, bev_cpu = cpu_baseline(cfg, ecfg, sd, host_frames[0], args.workload)
+            cb, bev_cpu = cpu_baseline(cfg, ecfg, sd, host_frames[0], args.workload, args.cpu_passes)
             line['cpu_baseline'] = cb
             if B == 1 and args.dtype == 'f32':  # same frame, same math: the GPU result must match
                 with torch.no_grad():

@@ -276,6 +276,11 @@ SF_API int sf_sparse_conv_bf16(const void *features_in, int n_in_bound, int cin_
                                const float *shift, const void *residual, int relu, void *out,
                                int out_is_f32, const int *n_out_dev, int n_out_bound, void *stream);
 
+/* Name of the convolution kernel the calling thread launched last, template arguments included,
+ * exactly as a rocprofv3 kernel trace prints it (minus the anonymous namespace and the argument
+ * list): bench.py's roofline.kernel.  No reference counterpart (diagnostic). */
+SF_API const char *sf_last_conv_kernel(void);
+
 /* ---- the same convolution over mask-ordered rows (csrc/spconv_f32_ordered.hip) ---- */
 
 /* Workspace bytes of sf_row_order_by_mask for up to n_bound output rows. */

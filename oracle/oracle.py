@@ -56,6 +56,8 @@ def lib():
         L.sfo_dense_bev.argtypes = [_f32p, _i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_int, _f32p]
         L.sfo_num_threads.restype = C.c_int
+        L.sfo_set_num_threads.argtypes = [C.c_int]
+        L.sfo_conv_stage_times.argtypes = [C.POINTER(C.c_double), C.c_int]
         _LIB = L
     return _LIB
 
@@ -298,6 +300,13 @@ def canonical_rulebook(in_indices, in_shape, outids, out_shape, pairs, num):
 
 
 # ---------------------------------------------------------------- conv
+
+def conv_stage_times(reset=True):
+    """(gather, GEMM, scatter-add) seconds spent inside indice_conv since the last reset."""
+    buf = (C.c_double * 3)()
+    lib().sfo_conv_stage_times(buf, int(bool(reset)))
+    return tuple(float(v) for v in buf)
+
 
 def indice_conv(features, filters_kio, pairs, num, n_out, subm):
     """filters_kio: (K, Cin, Cout) fp32 (spconv-1.x layout flattened)."""

@@ -309,6 +309,23 @@ static void sfo_gemm(const float *a, int rows, int cin, const float *w, int cout
  * filters (K,cin,cout) [= (kD,kH,kW,cin,cout) viewed, spconv_ops.h:299],
  * pairs (K,2,L), num (K).  out (n_out,cout) is overwritten.
  * Returns 0, or -1 on allocation failure. */
+/* Wall time spent in the three stages of sfo_indice_conv since the last reset (bench.py's
+ * cpu_baseline breakdown: gather / GEMM / scatter-add). */
+static double sfo_t_stage[3];
+static double sfo_now(void) {
+#ifdef _OPENMP
+  return omp_get_wtime();
+#else
+  return 0.0;
+#endif
+}
+SFO_API void sfo_conv_stage_times(double out3[3], int reset) {
+  for (int i = 0; i < 3; ++i) {
+    out3[i] = sfo_t_stage[i];
+    if (reset) sfo_t_stage[i] = 0.0;
+  }
+}
+
 SFO_API int sfo_indice_conv(const float *feat, int n_in, int cin, const float *filt, int cout,
                             const int *pairs, const int *num, int K, int L, int n_out,
                             int subm, float *out) {
@@ -328,21 +345,29 @@ SFO_API int sfo_indice_conv(const float *feat, int n_in, int cin, const float *f
     free(obuf);
     return -1;
   }
+  double t0 = sfo_now();
   if (subm) /* centre offset without gather/scatter (:300-303) */
     sfo_gemm(feat, n_out, cin, filt + (size_t)kmax * cin * cout, cout, out);
+  sfo_t_stage[1] += sfo_now() - t0;
   for (int k = 0; k < K; ++k) {
     int nhot = num[k];
     if (nhot <= 0 || (subm && k == kmax)) continue;
     const int *pin = pairs + ((size_t)k * 2 + 0) * L;
     const int *pout = pairs + ((size_t)k * 2 + 1) * L;
+    t0 = sfo_now();
     for (int i = 0; i < nhot; ++i) /* reordering.cc:26-30 */
       memcpy(ibuf + (size_t)i * cin, feat + (size_t)pin[i] * cin, sizeof(float) * cin);
+    double t1 = sfo_now();
     sfo_gemm(ibuf, nhot, cin, filt + (size_t)k * cin * cout, cout, obuf);
+    double t2 = sfo_now();
     for (int i = 0; i < nhot; ++i) { /* reordering.cc:42-48 */
       float *o = out + (size_t)pout[i] * cout;
       const float *b = obuf + (size_t)i * cout;
       for (int q = 0; q < cout; ++q) o[q] += b[q];
     }
+    sfo_t_stage[0] += t1 - t0;
+    sfo_t_stage[1] += t2 - t1;
+    sfo_t_stage[2] += sfo_now() - t2;
   }
   free(ibuf);
   free(obuf);
@@ -451,6 +476,14 @@ SFO_API int sfo_dynamic_scatter(const float *feats, const int *coors, int n, int
   free(uniq);
   free(ids);
   return nv;
+}
+
+SFO_API void sfo_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n >= 1) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
 }
 
 SFO_API int sfo_num_threads(void) {

@@ -11,6 +11,9 @@
 #define SF_WAVE 64
 
 void sf_set_error(const char *fmt, ...);
+// name (template arguments included, as a rocprofv3 kernel trace prints it) of the convolution
+// kernel this thread launched last: sf_last_conv_kernel()
+void sf_note_kernel(const char *fmt, ...);
 
 #define SF_CHECK_ARG(cond, ...)          \
   do {                                   \

@@ -428,6 +428,7 @@ struct ConvArgs {
 
 template <int CIN, int COUT, int MB, int D1>
 int launch_direct(const ConvArgs &a) {
+  sf_note_kernel("conv_bf16_direct_kernel<%d, %d, %d, %d>", CIN, COUT, MB, D1);
   hipLaunchKernelGGL((conv_bf16_direct_kernel<CIN, COUT, MB, D1>),
                      dim3((sf_div_up(a.n_out_bound, 16 * MB * 4) + 7) & ~7), dim3(256), 0, a.st, a.feat,
                      a.feat_bytes, a.nbr, a.nbr_stride, a.k_first, a.wpk, a.scale, a.shift,
@@ -463,6 +464,7 @@ int launch_tile(const ConvArgs &a) {
     int grid = (sf_div_up(a.n_out_bound, balance ? 16 : TM) + 7) & ~7;
     const int cap = balance ? slots : 8192;
     if (grid > cap) grid = cap;
+    sf_note_kernel("conv_bf16_tile_kernel<%d, %d, %d, %d, 4, 2>", CIN, COUT, TM, CG);
     hipLaunchKernelGGL((conv_bf16_tile_kernel<CIN, COUT, TM, CG, 4, 2>), dim3(grid), dim3(256), 0,
                        a.st, a.feat, a.feat_bytes, a.nbr, a.nbr_stride, a.K, a.k_first, a.wpk,
                        a.scale, a.shift, a.residual, a.relu, a.out, a.out_f32, a.n_out_dev,

@@ -951,6 +951,7 @@ int launch(const ConvArgs &a, int balance_default) {
   int tiles = sf_div_up(a.n_out_bound, balance ? 32 : TM);
   int cap = balance ? slots : 4096;
   int grid = tiles < cap ? tiles : cap;
+  sf_note_kernel("sparse_conv_f32_kernel<%d, %d, %d, %d, %d, %d>", CIN, COUT, TM, AM, WAVES, ABUF);
   hipLaunchKernelGGL((sparse_conv_f32_kernel<CIN, COUT, TM, AM, WAVES, ABUF>), dim3(grid),
                      dim3(WAVES * 64), 0, a.st, a.feat, a.nbr, a.nbr_stride, a.K, a.k_first, a.wpk,
                      a.scale, a.shift, a.residual, a.relu, a.out, a.n_out_dev, a.n_out_bound,
@@ -988,6 +989,7 @@ int launch_wide(const ConvArgs &a, int balance_default) {
     int tiles = sf_div_up(a.n_out_bound, balance ? 32 : TM);
     int cap = balance ? slots : 4096;
     int grid = tiles < cap ? tiles : cap;
+    sf_note_kernel("sparse_conv_f32_wide_kernel<%d, %d, %d, %d, %d, %d>", CIN, COUT, TM, AM, WAVES, MINW);
     hipLaunchKernelGGL((sparse_conv_f32_wide_kernel<CIN, COUT, TM, AM, WAVES, MINW>), dim3(grid),
                        dim3(WAVES * 64), 0, a.st, a.feat, a.nbr, a.nbr_stride, a.K, a.k_first, a.wpk,
                        a.scale, a.shift, a.residual, a.relu, a.out, a.n_out_dev, a.n_out_bound,
@@ -1000,6 +1002,7 @@ int launch_wide(const ConvArgs &a, int balance_default) {
 template <int CIN, int COUT, int MB, int D1>
 int launch_direct(const ConvArgs &a) {
   const int rows_per_block = 16 * MB * 4;
+  sf_note_kernel("sparse_conv_f32_direct_kernel<%d, %d, %d, %d>", CIN, COUT, MB, D1);
   hipLaunchKernelGGL((sparse_conv_f32_direct_kernel<CIN, COUT, MB, D1>),
                      dim3(sf_div_up(a.n_out_bound, rows_per_block)), dim3(256), 0, a.st, a.feat,
                      a.nbr, a.nbr_stride, a.k_first, a.wpk, a.scale, a.shift, a.residual, a.relu,

@@ -169,6 +169,7 @@ int launch_narrow(const SfConvArgs &a) {
   const int tiles = sf_div_up(a.n_out_bound, 16);
   int grid = (sf_div_up(tiles, WAVES) + 7) & ~7;     // one tile per wave is the least useful grid
   if (grid > slots) grid = slots;
+  sf_note_kernel("narrow_conv_f32_kernel<%d, %d, %s, %d, %d>", CIN, COUT, SUBM ? "true" : "false", D, WAVES);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, a.st, a.feat, a.nbr, a.nbr_stride, a.wpk,
                      a.scale, a.shift, a.residual, a.relu, a.out, a.n_out_dev, a.n_out_bound);
   SF_CHECK_LAUNCH();

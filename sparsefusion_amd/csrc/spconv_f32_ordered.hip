@@ -615,6 +615,7 @@ int launch_ordered(const OrdArgs &a) {
   }
   const int tiles = plan_tiles(a.n_out_bound);
   const int grid = tiles < slots ? tiles : slots;
+  sf_note_kernel("conv_f32_ordered_kernel<%d, %d, %d, %d, %d>", CIN, COUT, CG, WAVES, MINB);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, a.st, a.feat, a.feat_bytes,
                      plan_view(a.plan, a.n_out_bound), a.K, a.k_first,
                      reinterpret_cast<const f32x4 *>(a.wpk), a.scale, a.shift, a.residual, a.relu,

@@ -39,3 +39,18 @@ def gather_results(local):
     for d in out:
         merged.update(d)
     return merged
+
+
+def verify_frames(merged, expected_ids, rechecks=()):
+    """Fail loudly when the job did not produce what a single process would have:
+    every frame id of `expected_ids` must be present in `merged` (the gather_results dict), and every
+    (frame_id, digest) in `rechecks` -- a frame recomputed on ANOTHER rank -- must equal the owning
+    rank's digest.  A sharded run that silently dropped or corrupted a frame is not a result."""
+    missing = sorted(i for i in expected_ids if i not in merged)
+    if missing:
+        raise RuntimeError(f'frames missing from the gathered results: {missing}')
+    for fid, digest in rechecks:
+        if merged[fid] != digest:
+            raise RuntimeError(f'frame {fid}: digest {merged[fid]} on its rank, {digest} when another '
+                               f'rank recomputed it')
+    return len(expected_ids)

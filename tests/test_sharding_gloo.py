@@ -19,6 +19,22 @@ def _worker(rank, world, port, n_frames, q):
         local = {f: sharding.checksum(np.full(8, f, np.float32)) for f in mine}
         merged = sharding.gather_results(local)
         t = sharding.max_over_ranks(1.0 + rank)
+        # the cross-check bench.py runs at N>1: the next rank recomputes frame 0 and every rank
+        # verifies the merged table (complete, and the recomputed digest equal to the owner's)
+        recheck = {('recheck', 0): sharding.checksum(np.full(8, 0, np.float32))} if rank == 1 % world else {}
+        extra = sharding.gather_results(recheck)
+        ok = sharding.verify_frames(merged, range(n_frames), [(0, extra[('recheck', 0)])])
+        bad = None
+        try:
+            sharding.verify_frames(merged, range(n_frames + 1))
+        except RuntimeError as e:
+            bad = str(e)
+        try:
+            sharding.verify_frames(merged, range(n_frames), [(0, 'deadbeef')])
+            bad2 = None
+        except RuntimeError as e:
+            bad2 = str(e)
+        assert ok == n_frames and 'missing' in bad and 'recomputed' in bad2
         q.put((rank, mine, sorted(merged), t, merged[n_frames - 1]))
     finally:
         dist.destroy_process_group()

@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
-"""profiles/r01_hbm_rates.md: measured HBM GB/s per kernel = PMC bytes per launch
-(profiles/r01_pmc_hbm_traffic*.json, tools/pmc_traffic.sh) / average launch duration of the rocprofv3
-trace (profiles/r01_bench_nusc_*_kernel_stats.csv, tools/prof_bench.sh).  Run after refreshing both."""
+"""profiles/<round>_hbm_rates.md (usage: tools/hbm_rates.py r02): measured HBM GB/s per kernel = PMC bytes per launch
+(profiles/<round>_pmc_hbm_traffic*.json, tools/pmc_traffic.sh) / average launch duration of the rocprofv3
+trace (profiles/<round>_bench_nusc_*_kernel_stats.csv, tools/prof_bench.sh).  Run after refreshing both."""
 import csv
 import json
 import os
 import re
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RND = sys.argv[1] if len(sys.argv) > 1 else 'r02'     # round prefix of the profile files
 
 
 def table(stats_csv, traffic_json):
@@ -28,10 +30,10 @@ def table(stats_csv, traffic_json):
     return '\n'.join(out)
 
 
-HEAD = '''# Measured HBM rates per kernel (round 1)
+HEAD = f'''# Measured HBM rates per kernel ({RND})
 
-Average launch duration from the rocprofv3 kernel trace of `python bench.py` (`r01_bench_nusc_*_kernel_stats.csv`),
-HBM-side bytes per launch from the separate PMC passes (`r01_pmc_hbm_traffic*.json`: FETCH_SIZE doubled as the
+Average launch duration from the rocprofv3 kernel trace of `python bench.py` (`{RND}_bench_nusc_*_kernel_stats.csv`),
+HBM-side bytes per launch from the separate PMC passes (`{RND}_pmc_hbm_traffic*.json`: FETCH_SIZE doubled as the
 gfx950 note in MI355X_MICROARCH.md prescribes, WRITE_SIZE as read; eager run over the same 4 frames).  These are
 the bytes that reach HBM / Infinity Cache: feature tables of 8-85 MB mostly live in L2 / MALL, so the
 convolutions' rates sit far below their ALGORITHMIC rates (DESIGN.md section 3), which count every gathered row;
@@ -41,9 +43,11 @@ regenerates this file.
 
 if __name__ == '__main__':
     md = HEAD + '\n## fp32 (BASELINE configs[1])\n\n' + table(
-        'profiles/r01_bench_nusc_f32_kernel_stats.csv', 'profiles/r01_pmc_hbm_traffic.json')
-    md += '\n\n## bf16 (BASELINE configs[2], B = 1)\n\n' + table(
-        'profiles/r01_bench_nusc_bf16_kernel_stats.csv', 'profiles/r01_pmc_hbm_traffic_bf16.json') + '\n'
-    with open(os.path.join(ROOT, 'profiles', 'r01_hbm_rates.md'), 'w') as f:
+        f'profiles/{RND}_bench_nusc_f32_kernel_stats.csv', f'profiles/{RND}_pmc_hbm_traffic.json')
+    if os.path.exists(os.path.join(ROOT, f'profiles/{RND}_pmc_hbm_traffic_bf16.json')):
+        md += '\n\n## bf16 (BASELINE configs[2], B = 1)\n\n' + table(
+            f'profiles/{RND}_bench_nusc_bf16_kernel_stats.csv', f'profiles/{RND}_pmc_hbm_traffic_bf16.json')
+    md += '\n'
+    with open(os.path.join(ROOT, 'profiles', f'{RND}_hbm_rates.md'), 'w') as f:
         f.write(md)
     print(md)
