@@ -303,7 +303,7 @@ __host__ __device__ inline int plan_tiles(int n_bound) { return (n_bound + kTile
 //   (5) parks the rows of phase q+1 in the other LDS buffer;  one barrier.
 // Tiles are padded to three phases so that the look-ahead crosses at most one tile boundary; tile
 // headers travel through a ring of three LDS slots, loaded two tiles ahead.
-template <int CIN, int COUT, int CG, int WAVES, int MINB>
+template <int CIN, int COUT, int CG, int WAVES, int MINB, int BFD>
 __global__ void __launch_bounds__(WAVES * 64, MINB)
 conv_f32_ordered_kernel(const float *__restrict__ feat, unsigned feat_bytes, PlanView pv, int K,
                         int k_first, const f32x4 *__restrict__ wp, const float *__restrict__ scale,
@@ -339,7 +339,7 @@ conv_f32_ordered_kernel(const float *__restrict__ feat, unsigned feat_bytes, Pla
 
   f32x4 acc[MBW][NBW];
   u32x4 greg[2][GI];
-  f32x4 bf[2][NBW][T];
+  f32x4 bf[BFD][NBW][T];   // BFD = 1: one filter set, reloaded behind the multiply that used it
   int ireg[GI], orow[MBW];
 #pragma unroll
   for (int m = 0; m < GI; ++m) {
@@ -419,7 +419,7 @@ conv_f32_ordered_kernel(const float *__restrict__ feat, unsigned feat_bytes, Pla
         const int *ip = pv.nbrs + (size_t)(iD & 31) * pv.s_stride + (size_t)tD * TM;
 #pragma unroll
         for (int m = 0; m < GI; ++m) inew[m] = ip[(tid + m * NT) / CH];
-        {
+        if constexpr (BFD == 2) {
           const int k1 = iB & 31;
 #pragma unroll
           for (int i = 0; i < NBW; ++i)
@@ -477,7 +477,7 @@ conv_f32_ordered_kernel(const float *__restrict__ feat, unsigned feat_bytes, Pla
               for (int mb = 0; mb < MBW; ++mb)
 #pragma unroll
                 for (int i = 0; i < NBW; ++i)
-                  acc[mb][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[par][i][t][j], a[t & 1][mb][j],
+                  acc[mb][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[BFD == 2 ? par : 0][i][t][j], a[t & 1][mb][j],
                                                                    acc[mb][i], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
           }
@@ -493,12 +493,20 @@ conv_f32_ordered_kernel(const float *__restrict__ feat, unsigned feat_bytes, Pla
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                   for (int i = 0; i < NBW; ++i)
-                    acc[mb][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[par][i][t][j], av[j],
+                    acc[mb][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[BFD == 2 ? par : 0][i][t][j], av[j],
                                                                      acc[mb][i], 0, 0, 0);
               }
             }
           }
         }
+      }
+      if constexpr (BFD == 1) {   // the one filter set is free again: filters of phase q+1
+        const int k1 = iB & 31;
+#pragma unroll
+        for (int i = 0; i < NBW; ++i)
+#pragma unroll
+          for (int t = 0; t < T; ++t)
+            bf[0][i][t] = wp[(((size_t)k1 * NB + (cg * NBW + i)) * T + t) * 64 + lane];
       }
       const unsigned long long ts2 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
       if (fl & 4) {
@@ -594,11 +602,11 @@ PlanView plan_view(const int *plan, int n_bound) {
   return v;
 }
 
-template <int CIN, int COUT, int CG, int WAVES, int MINB>
+template <int CIN, int COUT, int CG, int WAVES, int MINB, int BFD = 2>
 int launch_ordered(const OrdArgs &a) {
   constexpr size_t lds = (size_t)2 * kTileRows * (CIN / 4) * 16 + (size_t)(3 * kHdrInts + 128) * 4;
   static_assert(lds <= 160 * 1024, "tile does not fit LDS");
-  auto kern = conv_f32_ordered_kernel<CIN, COUT, CG, WAVES, MINB>;
+  auto kern = conv_f32_ordered_kernel<CIN, COUT, CG, WAVES, MINB, BFD>;
   static int slots = 0;          // resident workgroups on the device
   if (slots == 0) {
     if (lds > 48 * 1024)
@@ -615,7 +623,7 @@ int launch_ordered(const OrdArgs &a) {
   }
   const int tiles = plan_tiles(a.n_out_bound);
   const int grid = tiles < slots ? tiles : slots;
-  sf_note_kernel("conv_f32_ordered_kernel<%d, %d, %d, %d, %d>", CIN, COUT, CG, WAVES, MINB);
+  sf_note_kernel("conv_f32_ordered_kernel<%d, %d, %d, %d, %d, %d>", CIN, COUT, CG, WAVES, MINB, BFD);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, a.st, a.feat, a.feat_bytes,
                      plan_view(a.plan, a.n_out_bound), a.K, a.k_first,
                      reinterpret_cast<const f32x4 *>(a.wpk), a.scale, a.shift, a.residual, a.relu,
@@ -631,9 +639,12 @@ int dispatch_ordered(int cout, const OrdArgs &a) {
   switch (cout) {
     case 16: return launch_ordered<CIN, 16, 1, 4, 2>(a);
     case 32: return launch_ordered<CIN, 32, 2, 4, 2>(a);
-    case 64: return launch_ordered<CIN, 64, 4, 4, 2>(a);   // (3 per CU spills: 146 -> 163 us at 64 -> 64)
+    // (one filter set everywhere it was measured: 64 -> 64 141 vs 143 us; 3 workgroups per CU spill)
+    case 64: return launch_ordered<CIN, 64, 4, 4, 2, 1>(a);
     case 128:
-      if constexpr (CIN >= 128) return launch_ordered<CIN, 128, 8, 8, 1>(a);
+      // (one filter set: 200 instead of 230 VGPRs, 194 vs 200 us; four waves with two column
+      // blocks each spill at 256)
+      if constexpr (CIN >= 128) return launch_ordered<CIN, 128, 8, 8, 1, 1>(a);
       else return launch_ordered<CIN, 128, 4, 4, 2>(a);
   }
   sf_set_error("unsupported cout=%d (16, 32, 64 or 128)", cout);
