@@ -92,7 +92,7 @@ SF_API int sf_hard_voxelize(const float *points, int n, int f, const float voxel
  * count from *row_count_dev): the scratch is a file-scope device array of SF_STATIC_SCRATCH_BYTES
  * that every GPU the library runs on holds until the process ends.  The call performs no
  * hipMalloc / hipFree and no host synchronisation.
- *  Limit: sf_hard_voxelize_workspace(n, max_points) <= SF_STATIC_SCRATCH_BYTES (about 349 000
+ *  Limit: sf_hard_voxelize_workspace(n, max_points) <= SF_STATIC_SCRATCH_BYTES (about 476 000
  *  points at max_points 10, i.e. a nuScenes-shaped 10-sweep frame), else SF_ERR_WORKSPACE.
  *  All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two
  *  host threads) race; serialise them.  Consecutive calls are independent (the scratch is

@@ -6,16 +6,23 @@
 // that would open voxel number max_voxels, and each voxel keeps its first max_points points.
 //
 // MI355X formulation (all integer / byte work, HBM- and atomic-bound, no serial step):
-//   fill    : hash keys <- EMPTY, per-slot point lists <- INT_MAX
-//   insert  : per point: coordinate -> hash slot (atomicCAS); then a bounded sorted insert of
-//             the point index into the slot's list of the max_points SMALLEST indices
-//             (a cascade of atomicMin: slot s keeps the min of everything offered to it and
-//             passes the rest on; the multiset is conserved, so the result is order independent)
-//   count   : flag "point i is the first point of its voxel" (list head == i), block sums
+//   fill    : hash slots (key, first point) <- (EMPTY, INT_MAX)              [8 bytes per slot]
+//   insert  : per point: coordinate -> hash slot (atomicCAS on the key), atomicMin of the point
+//             index into the slot's `first` word, which sits next to the key (one 64-byte line
+//             serves both); the point remembers its slot
+//   count   : flag "point i is the first point of its voxel" (first[slot] == i), block sums
 //   assign  : exclusive scan of the flags = voxel id in first-point order; the point whose
-//             voxel id equals max_voxels is the cut (reference `break`); writes coors
-//   write   : voxels[v][s][:] = points[list[s]] for list entries below the cut, zeros elsewhere
+//             voxel id equals max_voxels is the cut (reference `break`); writes coors, slot -> voxel
+//             id, and opens the voxel's point list (INT_MAX) in a table indexed by VOXEL ID
+//   collect : per point below the cut whose voxel survived: bounded sorted insert of the point
+//             index into the voxel's list of the max_points SMALLEST indices (a cascade of
+//             atomicMin: an entry keeps the min of everything offered to it and passes the rest on;
+//             the multiset is conserved, so the result is order independent)
+//   write   : voxels[v][s][:] = points[list[v][s]], zeros elsewhere
 //   reduce  : num_points_per_voxel and the fused HardSimpleVFE mean
+// The lists are dense by voxel id (max_voxels x max_points ints, L2 resident) and built only for the
+// voxels that survive the cut; round 1 kept a list per HASH SLOT (21 MB filled and probed at random
+// per frame: 146 MB at the fabric for a 6.4 MB cloud).
 #include <mutex>
 
 #include "sf_common.h"
@@ -58,13 +65,14 @@ __global__ void dynamic_voxelize_kernel(const float *__restrict__ points, int n,
 }
 
 // misc words: [0] cut point index, [1] voxel_num of this call, [2] overflow, [3] base row
-__global__ void vox_fill_kernel(uint32_t *__restrict__ keys, long long n_keys,
-                                int *__restrict__ lists, long long n_lists,
-                                int *__restrict__ misc, const int *__restrict__ row_count_dev) {
+// slot table: kf[2*slot] = key, kf[2*slot + 1] = smallest point index of the voxel
+__global__ void vox_fill_kernel(uint2 *__restrict__ kf, long long n_slots, int *__restrict__ misc,
+                                const int *__restrict__ row_count_dev) {
   long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = tid; i < n_keys; i += stride) keys[i] = SF_EMPTY_KEY;
-  for (long long i = tid; i < n_lists; i += stride) lists[i] = SF_INT_MAX;
+  const uint4 init = make_uint4(SF_EMPTY_KEY, (uint32_t)SF_INT_MAX, SF_EMPTY_KEY, (uint32_t)SF_INT_MAX);
+  uint4 *kf4 = reinterpret_cast<uint4 *>(kf);
+  for (long long i = tid; i < n_slots / 2; i += stride) kf4[i] = init;   // n_slots is a power of two
   if (tid == 0) {
     misc[0] = SF_INT_MAX;
     misc[1] = 0;
@@ -74,8 +82,7 @@ __global__ void vox_fill_kernel(uint32_t *__restrict__ keys, long long n_keys,
 }
 
 __global__ void vox_insert_kernel(const float *__restrict__ points, int n, int f, VoxParams vp,
-                                  int max_points, uint32_t *__restrict__ keys, uint32_t mask,
-                                  int *__restrict__ lists, int *__restrict__ pslot,
+                                  uint32_t *__restrict__ kf, uint32_t mask, int *__restrict__ pslot,
                                   int *__restrict__ misc) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     int c[3];
@@ -83,47 +90,50 @@ __global__ void vox_insert_kernel(const float *__restrict__ points, int n, int f
       pslot[i] = -1;
       continue;
     }
-    uint32_t key = ((uint32_t)c[0] * (uint32_t)vp.grid[1] + (uint32_t)c[1]) * (uint32_t)vp.grid[0] +
-                   (uint32_t)c[2];
-    int slot = sf_hash_insert(keys, mask, key);
-    pslot[i] = slot;
-    if (slot < 0) {  // cannot happen with capacity >= n; kept as a guard
+    const uint32_t key = ((uint32_t)c[0] * (uint32_t)vp.grid[1] + (uint32_t)c[1]) *
+                             (uint32_t)vp.grid[0] + (uint32_t)c[2];
+    uint32_t slot = sf_first_slot(key, mask);
+    int found = -1;
+    for (uint32_t probe = 0; probe <= mask; ++probe) {
+      uint32_t cur = kf[2 * (size_t)slot];
+      if (cur == SF_EMPTY_KEY) {
+        cur = atomicCAS(&kf[2 * (size_t)slot], SF_EMPTY_KEY, key);
+        if (cur == SF_EMPTY_KEY) cur = key;
+      }
+      if (cur == key) {
+        found = (int)slot;
+        break;
+      }
+      slot = (slot + 1) & mask;
+    }
+    pslot[i] = found;
+    if (found < 0) {  // cannot happen with capacity >= n; kept as a guard
       misc[2] = 1;
       continue;
     }
-    int *list = lists + (size_t)slot * max_points;
-    int v = i;
-    for (int s = 0; s < max_points; ++s) {
-      // entries only ever decrease, so a (possibly stale) smaller value means "not ours"
-      int cur = __builtin_nontemporal_load(list + s);
-      if (cur < v) continue;
-      int old = atomicMin(list + s, v);
-      if (old > v) v = old;  // we took the slot, carry the displaced value on
-      if (v == SF_INT_MAX) break;
-    }
+    atomicMin(reinterpret_cast<int *>(kf) + 2 * (size_t)found + 1, i);
   }
 }
 
 __device__ __forceinline__ bool is_first_point(int i, int n, const int *__restrict__ pslot,
-                                               const int *__restrict__ lists, int max_points,
-                                               int *slot_out) {
+                                               const uint32_t *__restrict__ kf, int *slot_out) {
   if (i >= n) return false;
   int slot = pslot[i];
   *slot_out = slot;
   if (slot < 0) return false;
-  return lists[(size_t)slot * max_points] == i;
+  return (int)kf[2 * (size_t)slot + 1] == i;
 }
 
 __global__ void __launch_bounds__(kThreads)
-vox_count_kernel(int n, int max_points, const int *__restrict__ pslot,
-                 const int *__restrict__ lists, int *__restrict__ bsum) {
+vox_count_kernel(int n, const int *__restrict__ pslot, const uint32_t *__restrict__ kf,
+                 int *__restrict__ bsum) {
   __shared__ int smem[17];
   int base = blockIdx.x * kChunk + threadIdx.x * kItems;
   int c = 0;
 #pragma unroll
   for (int e = 0; e < kItems; ++e) {
     int slot;
-    c += is_first_point(base + e, n, pslot, lists, max_points, &slot) ? 1 : 0;
+    c += is_first_point(base + e, n, pslot, kf, &slot) ? 1 : 0;
   }
   int total = sf_block_sum(c, smem);
   if (threadIdx.x == 0) bsum[blockIdx.x] = total;
@@ -131,11 +141,10 @@ vox_count_kernel(int n, int max_points, const int *__restrict__ pslot,
 
 __global__ void __launch_bounds__(kThreads)
 vox_assign_kernel(int n, int max_points, int max_voxels, VoxParams vp, const int *__restrict__ pslot,
-                  const int *__restrict__ lists, const uint32_t *__restrict__ keys,
-                  const int *__restrict__ bsum, int nblk, int *__restrict__ vox_slot,
-                  int *__restrict__ coors, int coors_stride, int batch_idx, int rows_capacity,
-                  int *__restrict__ misc, int *__restrict__ row_count_dev,
-                  int *__restrict__ overflow_dev) {
+                  const uint32_t *__restrict__ kf, const int *__restrict__ bsum, int nblk,
+                  int *__restrict__ slot_vid, int *__restrict__ lists, int *__restrict__ coors,
+                  int coors_stride, int batch_idx, int rows_capacity, int *__restrict__ misc,
+                  int *__restrict__ row_count_dev, int *__restrict__ overflow_dev) {
   __shared__ int smem[17];
   int before, all;
   sf_block_prefix_of(bsum, nblk, blockIdx.x, smem, &before, &all);
@@ -147,7 +156,7 @@ vox_assign_kernel(int n, int max_points, int max_voxels, VoxParams vp, const int
 #pragma unroll
   for (int e = 0; e < kItems; ++e) {
     int slot = -1;
-    bool f = is_first_point(base + e, n, pslot, lists, max_points, &slot);
+    bool f = is_first_point(base + e, n, pslot, kf, &slot);
     slots[e] = slot;
     flags |= (f ? 1u : 0u) << e;
     c += f ? 1 : 0;
@@ -158,11 +167,15 @@ vox_assign_kernel(int n, int max_points, int max_voxels, VoxParams vp, const int
   for (int e = 0; e < kItems; ++e) {
     if (!((flags >> e) & 1u)) continue;
     if (max_voxels >= 0 && vid == max_voxels) misc[0] = base + e;  // the reference's `break`
-    if (max_voxels < 0 || vid < max_voxels) {
-      vox_slot[vid] = slots[e];
+    const bool keep = max_voxels < 0 || vid < max_voxels;
+    slot_vid[slots[e]] = keep ? vid : -1;
+    if (keep) {
+      int *list = lists + (size_t)vid * max_points;
+      list[0] = base + e;   // the first point is the smallest index: it opens the list
+      for (int s = 1; s < max_points; ++s) list[s] = SF_INT_MAX;
       int row = base_row + vid;
       if (row < rows_capacity) {
-        uint32_t key = keys[slots[e]];
+        uint32_t key = kf[2 * (size_t)slots[e]];
         uint32_t gx = (uint32_t)vp.grid[0], gy = (uint32_t)vp.grid[1];
         int x = (int)(key % gx);
         uint32_t zy = key / gx;
@@ -189,10 +202,38 @@ vox_assign_kernel(int n, int max_points, int max_voxels, VoxParams vp, const int
   }
 }
 
+// second pass over the points: the lists of the surviving voxels
+__global__ void vox_collect_kernel(int n, int max_points, const int *__restrict__ pslot,
+                                   const int *__restrict__ slot_vid, const int *__restrict__ misc,
+                                   int *__restrict__ lists) {
+  const int cut = misc[0];
+  const int stop = cut < n ? cut : n;   // points from the cut on belong to no voxel
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < stop; i += gridDim.x * blockDim.x) {
+    const int slot = pslot[i];
+    if (slot < 0) continue;
+    const int vid = slot_vid[slot];
+    if (vid < 0) continue;
+    int *list = lists + (size_t)vid * max_points;
+    int v = i;
+    // crowded voxels: once the list holds max_points smaller indices this point has no place in it
+    // (entries only ever decrease, so a stale read errs on the safe side)
+    if (__builtin_nontemporal_load(list + max_points - 1) < v) continue;
+    for (int s = 0; s < max_points; ++s) {
+      // a (possibly stale) smaller value means "not ours"
+      int cur = __builtin_nontemporal_load(list + s);
+      if (cur < v) continue;
+      if (cur == v) break;   // the voxel's first point: already in place (vox_assign)
+      int old = atomicMin(list + s, v);
+      if (old > v) v = old;  // we took the entry, carry the displaced value on
+      if (v == SF_INT_MAX) break;
+    }
+  }
+}
+
 __global__ void vox_write_kernel(const float *__restrict__ points, int f, int max_points,
-                                 const int *__restrict__ lists, const int *__restrict__ vox_slot,
-                                 const int *__restrict__ misc, float *__restrict__ voxels) {
-  const int vnum = misc[1], cut = misc[0], base_row = misc[3];
+                                 const int *__restrict__ lists, const int *__restrict__ misc,
+                                 float *__restrict__ voxels) {
+  const int vnum = misc[1], base_row = misc[3];
   const long long total = (long long)vnum * max_points * f;
   const int per_voxel = max_points * f;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
@@ -200,8 +241,8 @@ __global__ void vox_write_kernel(const float *__restrict__ points, int f, int ma
     int vid = (int)(e / per_voxel);
     int r = (int)(e - (long long)vid * per_voxel);
     int s = r / f, k = r - s * f;
-    int j = lists[(size_t)vox_slot[vid] * max_points + s];
-    float v = (j < cut) ? points[(size_t)j * f + k] : 0.0f;
+    int j = lists[(size_t)vid * max_points + s];
+    float v = (j != SF_INT_MAX) ? points[(size_t)j * f + k] : 0.0f;
     voxels[(size_t)(base_row + vid) * per_voxel + r] = v;
   }
 }
@@ -209,22 +250,22 @@ __global__ void vox_write_kernel(const float *__restrict__ points, int f, int ma
 // num_points_per_voxel (voxelization_cpu.cpp:89-95) + HardSimpleVFE mean (voxel_encoder.py:42-44:
 // sum over the slots in order, zeros included, divided by the count).
 __global__ void vox_reduce_kernel(const float *__restrict__ points, int f, int max_points,
-                                  const int *__restrict__ lists, const int *__restrict__ vox_slot,
-                                  const int *__restrict__ misc, int *__restrict__ npv,
-                                  float *__restrict__ mean, int mean_features, int mean_stride) {
-  const int vnum = misc[1], cut = misc[0], base_row = misc[3];
+                                  const int *__restrict__ lists, const int *__restrict__ misc,
+                                  int *__restrict__ npv, float *__restrict__ mean, int mean_features,
+                                  int mean_stride) {
+  const int vnum = misc[1], base_row = misc[3];
   const int cols = mean ? mean_stride : 1;
   const long long total = (long long)vnum * cols;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (long long)gridDim.x * blockDim.x) {
     int vid = (int)(e / cols), k = (int)(e - (long long)vid * cols);
-    const int *list = lists + (size_t)vox_slot[vid] * max_points;
+    const int *list = lists + (size_t)vid * max_points;
     int cnt = 0;
     float sum = 0.0f;
     const bool want = mean && k < mean_features;
     for (int s = 0; s < max_points; ++s) {
       int j = list[s];
-      if (j >= cut) break;  // lists ascend; INT_MAX marks empty
+      if (j == SF_INT_MAX) break;  // lists ascend; INT_MAX marks empty
       ++cnt;
       if (want) sum += points[(size_t)j * f + k];
     }
@@ -257,8 +298,8 @@ __global__ void voxel_mean_kernel(const float *__restrict__ voxels, const int *_
 size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct VoxWorkspace {
-  uint32_t *keys;
-  int *lists, *pslot, *bsum, *misc, *vox_slot;
+  uint32_t *kf;        // (key, first point) per hash slot
+  int *lists, *pslot, *bsum, *misc, *slot_vid;
   long long cap;
   int nblk;
   size_t bytes;
@@ -272,20 +313,21 @@ VoxWorkspace carve(void *ws, int n, int max_points) {
   while (cap < want) cap <<= 1;
   w.cap = cap;
   w.nblk = sf_div_up(n > 0 ? n : 1, kChunk);
+  const size_t nn = (size_t)(n > 0 ? n : 1);
   size_t off = 0;
   char *b = (char *)ws;
-  w.keys = (uint32_t *)(b + off);
+  w.kf = (uint32_t *)(b + off);
+  off += align_up((size_t)cap * 8);
+  w.slot_vid = (int *)(b + off);
   off += align_up((size_t)cap * 4);
-  w.lists = (int *)(b + off);
-  off += align_up((size_t)cap * (size_t)max_points * 4);
+  w.lists = (int *)(b + off);          // by voxel id: at most one voxel per point
+  off += align_up(nn * (size_t)max_points * 4);
   w.pslot = (int *)(b + off);
-  off += align_up((size_t)(n > 0 ? n : 1) * 4);
+  off += align_up(nn * 4);
   w.bsum = (int *)(b + off);
   off += align_up((size_t)w.nblk * 4);
   w.misc = (int *)(b + off);
   off += align_up(64);
-  w.vox_slot = (int *)(b + off);
-  off += align_up((size_t)(n > 0 ? n : 1) * 4);
   w.bytes = off;
   return w;
 }
@@ -360,36 +402,37 @@ int hard_voxelize_impl(const float *points, int n, int f, const float voxel_size
   }
   SF_CHECK_ARG(n == 0 || points, "points is NULL");
 
-  const long long n_lists = w.cap * (long long)max_points;
-  hipLaunchKernelGGL(vox_fill_kernel, dim3(sf_grid(n_lists, kThreads)), dim3(kThreads), 0, st,
-                     w.keys, w.cap, w.lists, n_lists, w.misc, (const int *)row_count_dev);
+  hipLaunchKernelGGL(vox_fill_kernel, dim3(sf_grid(w.cap / 2, kThreads)), dim3(kThreads), 0, st,
+                     reinterpret_cast<uint2 *>(w.kf), w.cap, w.misc, (const int *)row_count_dev);
   SF_CHECK_LAUNCH();
   if (n > 0) {
     hipLaunchKernelGGL(vox_insert_kernel, dim3(sf_grid(n, kThreads)), dim3(kThreads), 0, st, points,
-                       n, f, vp, max_points, w.keys, (uint32_t)(w.cap - 1), w.lists, w.pslot,
-                       w.misc);
+                       n, f, vp, w.kf, (uint32_t)(w.cap - 1), w.pslot, w.misc);
     SF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(vox_count_kernel, dim3(w.nblk), dim3(kThreads), 0, st, n, max_points,
-                       (const int *)w.pslot, (const int *)w.lists, w.bsum);
+    hipLaunchKernelGGL(vox_count_kernel, dim3(w.nblk), dim3(kThreads), 0, st, n,
+                       (const int *)w.pslot, (const uint32_t *)w.kf, w.bsum);
     SF_CHECK_LAUNCH();
     hipLaunchKernelGGL(vox_assign_kernel, dim3(w.nblk), dim3(kThreads), 0, st, n, max_points,
-                       max_voxels, vp, (const int *)w.pslot, (const int *)w.lists,
-                       (const uint32_t *)w.keys, (const int *)w.bsum, w.nblk, w.vox_slot, coors,
-                       coors_stride, batch_idx, rows_capacity, w.misc, row_count_dev, overflow_dev);
+                       max_voxels, vp, (const int *)w.pslot, (const uint32_t *)w.kf,
+                       (const int *)w.bsum, w.nblk, w.slot_vid, w.lists, coors, coors_stride,
+                       batch_idx, rows_capacity, w.misc, row_count_dev, overflow_dev);
+    SF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(vox_collect_kernel, dim3(sf_grid(n, kThreads)), dim3(kThreads), 0, st, n,
+                       max_points, (const int *)w.pslot, (const int *)w.slot_vid,
+                       (const int *)w.misc, w.lists);
     SF_CHECK_LAUNCH();
     long long bound_v = (max_voxels >= 0 && max_voxels < n) ? max_voxels : n;
     if (voxels) {
       hipLaunchKernelGGL(vox_write_kernel, dim3(sf_grid(bound_v * max_points * f, kThreads)),
                          dim3(kThreads), 0, st, points, f, max_points, (const int *)w.lists,
-                         (const int *)w.vox_slot, (const int *)w.misc, voxels);
+                         (const int *)w.misc, voxels);
       SF_CHECK_LAUNCH();
     }
     if (num_points_per_voxel || mean) {
       long long cols = mean ? mean_stride : 1;
       hipLaunchKernelGGL(vox_reduce_kernel, dim3(sf_grid(bound_v * cols, kThreads)), dim3(kThreads),
-                         0, st, points, f, max_points, (const int *)w.lists,
-                         (const int *)w.vox_slot, (const int *)w.misc, num_points_per_voxel, mean,
-                         mean_features, mean_stride);
+                         0, st, points, f, max_points, (const int *)w.lists, (const int *)w.misc,
+                         num_points_per_voxel, mean, mean_features, mean_stride);
       SF_CHECK_LAUNCH();
     }
   }
