@@ -355,6 +355,7 @@ conv_f32_ordered_kernel(const float *__restrict__ feat, unsigned feat_bytes, Pla
 
   unsigned long long pt[6] = {0, 0, 0, 0, 0, 0};
   const unsigned long long tk0 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
+  const unsigned long long tr0 = prof ? __builtin_amdgcn_s_memrealtime() : 0ull;
   for (int run0 = 0; run0 < my_n; run0 += kRun) {
     const int cnt = (my_n - run0 < kRun) ? my_n - run0 : kRun;
     __syncthreads();   // the previous run is drained
@@ -573,6 +574,264 @@ conv_f32_ordered_kernel(const float *__restrict__ feat, unsigned feat_bytes, Pla
     for (int i = 0; i < 6; ++i) atomicAdd(&prof[i], pt[i]);
     atomicAdd(&prof[6], (unsigned long long)__builtin_amdgcn_s_memtime() - tk0);
     atomicAdd(&prof[7], 1ull);
+    atomicAdd(&prof[8], (unsigned long long)__builtin_amdgcn_s_memrealtime() - tr0);   // 100 MHz ticks
+  }
+}
+
+// One 16-byte-per-lane gather straight into LDS: lane L's chunk lands at lds + 16 L.  (The host pass
+// of hipcc cannot type the LDS address-space cast and would silently drop the kernel's stub, so the
+// body exists in the device pass only.)
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, unsigned char *lds, unsigned voff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)lds, 16, voff,
+                                           0, 0, 0);
+#else
+  (void)rs; (void)lds; (void)voff;
+#endif
+}
+
+// ---- the same kernel with the gathers written straight into LDS (LDS-DMA) ----------------------
+// `buffer_load_dwordx4 ... lds`: a wave-instruction writes 1 KiB of LDS linearly (lane L -> base +
+// 16 L), the per-lane SOURCE offset makes it a row gather, and an out-of-range source still writes
+// zeros.  No staging registers: the rows of phase q+2 go from L2 into one of THREE LDS buffers while
+// phases q and q+1 multiply from the other two, and the kernel fits 3 workgroups per CU (the
+// register-staged version needs 178 VGPRs at 64 channels).  The XOR swizzle of the LDS tile moves to
+// the source side: lane (row p, slot s) fetches chunk s ^ swz(p), the MFMA side reads chunk c at slot
+// c ^ swz(p) as before.  The three buffers are three __shared__ objects addressed with compile-time
+// indices (the phase loop is unrolled by three), so the compiler's alias analysis keeps the reads of
+// one buffer from waiting for the DMA into another; the only wait for the DMA is the hand-counted
+// s_waitcnt vmcnt(N) in front of the raw s_barrier that ends a phase (a __syncthreads() there
+// would drain every DMA in flight): N = the memory operations a wave issues after the DMA of phase
+// q+1 (issued one phase ago) = its index loads and filter loads of that phase and everything of this
+// one.  Conditional extras (tile start / end) only make the wait stronger.
+template <int CIN, int COUT, int CG, int WAVES, int MINB>
+__global__ void __launch_bounds__(WAVES * 64, MINB)
+conv_f32_dma_kernel(const float *__restrict__ feat, unsigned feat_bytes, PlanView pv, int K,
+                    int k_first, const f32x4 *__restrict__ wp, const float *__restrict__ scale,
+                    const float *__restrict__ shift, const float *__restrict__ residual, int relu,
+                    float *__restrict__ out, const int *n_out_dev, int n_out_bound) {
+  constexpr int TM = kTileRows, T = CIN / 16, ROWB = CIN * 4, CH = CIN / 4;
+  constexpr int NB = COUT / 16, NBW = NB / CG, RG = WAVES / CG, MBT = TM / 16, MBW = MBT / RG;
+  constexpr int RPI = 1024 / ROWB;             // rows one DMA instruction covers
+  constexpr int IPW = TM / RPI / WAVES;        // DMA instructions per wave and phase
+  constexpr int NBL = NBW * T;                 // filter loads per wave and phase
+  constexpr int kRun = 128, kLook = 3;
+  constexpr int kWaitN = 3 * IPW + 2 * NBL;    // see above
+  static_assert(NB % CG == 0 && WAVES % CG == 0 && MBT % RG == 0 && CIN >= 64 && (TM / RPI) % WAVES == 0 &&
+                    kWaitN < 64, "tile shape");
+
+  __shared__ __attribute__((aligned(1024))) unsigned char s_b0[TM * ROWB];
+  __shared__ __attribute__((aligned(1024))) unsigned char s_b1[TM * ROWB];
+  __shared__ __attribute__((aligned(1024))) unsigned char s_b2[TM * ROWB];
+  __shared__ int s_hdr[3 * kHdrInts];
+  __shared__ int s_tiles[kRun];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cg = wave % CG, rg = wave / CG;
+  const int g = lane >> 4, ln = lane & 15;
+  const int n_out = load_n(n_out_dev, n_out_bound);
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(feat), 0, feat_bytes, 0x00020000);
+  const int kf = (k_first >= 0 && k_first < K) ? k_first : -1;
+  const int tiles = (n_out + TM - 1) / TM;
+  const int G = gridDim.x, b = blockIdx.x;
+  const int full = tiles / G, rem = tiles - full * G;
+  const int my_n = full + ((((full & 1) ? G - 1 - b : b) < rem) ? 1 : 0);
+
+  f32x4 acc[MBW][NBW];
+  f32x4 bf[NBW][T];
+  int ireg[IPW], orow[MBW];
+  unsigned soff[IPW];        // source offset of this lane's chunk inside its row, per instruction
+  int prow[IPW];             // tile row this lane fetches, per instruction
+#pragma unroll
+  for (int j = 0; j < IPW; ++j) {
+    const int p = (wave * IPW + j) * RPI + lane / CH, slot = lane % CH;
+    prow[j] = p;
+    soff[j] = 16u * (unsigned)ATileF<CIN>::pos(p, slot);
+    ireg[j] = -1;
+  }
+#pragma unroll
+  for (int mb = 0; mb < MBW; ++mb) {
+    orow[mb] = -1;
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+      acc[mb][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NBW; ++i)
+#pragma unroll
+    for (int t = 0; t < T; ++t) bf[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int run0 = 0; run0 < my_n; run0 += kRun) {
+    const int cnt = (my_n - run0 < kRun) ? my_n - run0 : kRun;
+    __syncthreads();   // the previous run is drained (fence: every DMA has landed)
+    if (tid < cnt) {
+      const int i = run0 + tid;
+      s_tiles[tid] = pv.sched[(size_t)i * G + ((i & 1) ? G - 1 - b : b)];
+    }
+    __syncthreads();
+    if (tid < 2 * kHdrInts && (tid >> 5) < cnt)
+      s_hdr[tid] = pv.hdr[(size_t)s_tiles[tid >> 5] * kHdrInts + (tid & 31)];
+    __syncthreads();
+
+    int gj = 0, ga = 0;
+    int hcur = s_hdr[lane & 31], g_tile = __builtin_amdgcn_readfirstlane(s_tiles[0]);
+    auto next_desc = [&](int &d_tile, int &d_info) {
+      d_tile = 0;
+      d_info = 0;
+      if (gj < cnt) {
+        const int nact = __builtin_amdgcn_readlane(hcur, 0), np = nact > kLook ? nact : kLook;
+        int li = ga;
+        if (kf >= 0) {
+          const unsigned am = (unsigned)__builtin_amdgcn_readlane(hcur, 29);
+          if ((am >> kf) & 1u) {
+            const int pc = __popc(am & ((1u << kf) - 1u));
+            li = ga == 0 ? pc : (ga <= pc ? ga - 1 : ga);
+          }
+        }
+        const int e = ga < nact ? __builtin_amdgcn_readlane(hcur, 1 + (li < 27 ? li : 0)) : 0;
+        d_tile = g_tile;
+        d_info = (e & 31) | (((e >> 8) & 15) << 5) |
+                 (((ga < nact ? 1 : 0) | (ga == 0 ? 2 : 0) | (ga == np - 1 ? 4 : 0) | (ga == 1 ? 8 : 0) | 16) << 9);
+        if (++ga == np) {
+          ++gj;
+          ga = 0;
+          if (gj < cnt) {
+            hcur = s_hdr[(gj % 3) * kHdrInts + (lane & 31)];
+            g_tile = __builtin_amdgcn_readfirstlane(s_tiles[gj]);
+          }
+        }
+      }
+    };
+    int tA = 0, iA = 0, tB = 0, iB = 0, tC = 0, iC = 0, tD = 0, iD = 0;
+    int cj = -1, hreg = 0;
+
+    auto phase = [&](auto PH) {
+      constexpr int ph = decltype(PH)::value;              // q mod 3: buffer of this phase's rows
+      unsigned char *const cur = ph == 0 ? s_b0 : (ph == 1 ? s_b1 : s_b2);
+      unsigned char *const nxt2 = ph == 0 ? s_b2 : (ph == 1 ? s_b0 : s_b1);   // buffer of phase q+2
+      tA = tB; iA = iB; tB = tC; iB = iC; tC = tD; iC = iD;
+      next_desc(tD, iD);
+      // rows of phase q+2 -> LDS (indices loaded one phase ago), then the indices of phase q+3
+      {
+        const bool live = (iC >> 9) & 1;
+#pragma unroll
+        for (int j = 0; j < IPW; ++j) {
+          const int src = live ? ireg[j] : -1;   // -1: out of range, zeros land in LDS, no fetch
+          lds_dma16(rs, nxt2 + (wave * IPW + j) * 1024, (unsigned)src * ROWB + soff[j]);
+        }
+        const int *ip = pv.nbrs + (size_t)(iD & 31) * pv.s_stride + (size_t)tD * TM;
+#pragma unroll
+        for (int j = 0; j < IPW; ++j) ireg[j] = ip[prow[j]];
+      }
+      const int fl = iA >> 9;
+      if (fl & 2) {            // first phase of a tile
+        ++cj;
+#pragma unroll
+        for (int mb = 0; mb < MBW; ++mb) {
+          const int e = tA * TM + (rg * MBW + mb) * 16 + ln;
+          orow[mb] = e < n_out ? pv.order[e] : -1;
+#pragma unroll
+          for (int i = 0; i < NBW; ++i) acc[mb][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (tid < kHdrInts && cj + 2 < cnt) hreg = pv.hdr[(size_t)s_tiles[cj + 2] * kHdrInts + tid];
+      }
+      if (fl & 1) {
+        const int bmw = (iA >> (5 + rg * MBW)) & ((1 << MBW) - 1);
+        auto a_at = [&](int mb, int t) {
+          const int p = (rg * MBW + mb) * 16 + ln;
+          return *reinterpret_cast<const f32x4 *>(cur + p * ROWB + 16 * ATileF<CIN>::pos(p, 4 * t + g));
+        };
+        if (bmw == (1 << MBW) - 1) {
+          f32x4 a[2][MBW];
+#pragma unroll
+          for (int mb = 0; mb < MBW; ++mb) a[0][mb] = a_at(mb, 0);
+#pragma unroll
+          for (int t = 0; t < T; ++t) {
+            if (t + 1 < T) {
+#pragma unroll
+              for (int mb = 0; mb < MBW; ++mb) a[(t + 1) & 1][mb] = a_at(mb, t + 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int mb = 0; mb < MBW; ++mb)
+#pragma unroll
+                for (int i = 0; i < NBW; ++i)
+                  acc[mb][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[i][t][j], a[t & 1][mb][j],
+                                                                   acc[mb][i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else if (bmw != 0) {
+#pragma unroll
+          for (int mb = 0; mb < MBW; ++mb)
+            if ((bmw >> mb) & 1) {  // uniform
+#pragma unroll
+              for (int t = 0; t < T; ++t) {
+                const f32x4 av = a_at(mb, t);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                  for (int i = 0; i < NBW; ++i)
+                    acc[mb][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[i][t][j], av[j], acc[mb][i],
+                                                                     0, 0, 0);
+              }
+            }
+        }
+      }
+      {   // the one filter set is free again: filters of phase q+1
+        const int k1 = iB & 31;
+#pragma unroll
+        for (int i = 0; i < NBW; ++i)
+#pragma unroll
+          for (int t = 0; t < T; ++t)
+            bf[i][t] = wp[(((size_t)k1 * NB + (cg * NBW + i)) * T + t) * 64 + lane];
+      }
+      if (fl & 4) {   // end of a tile: folded BN, residual, ReLU, straight from the accumulators
+        f32x4 sc[NBW], sh[NBW], rsd[MBW][NBW];
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) {
+          const int c = (cg * NBW + i) * 16 + 4 * g;
+          sc[i] = scale ? *reinterpret_cast<const f32x4 *>(scale + c) : (f32x4){1.f, 1.f, 1.f, 1.f};
+          sh[i] = scale ? *reinterpret_cast<const f32x4 *>(shift + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int mb = 0; mb < MBW; ++mb) {
+            const int row = orow[mb] < 0 ? 0 : orow[mb];
+            rsd[mb][i] = residual ? *reinterpret_cast<const f32x4 *>(residual + (size_t)row * COUT + c)
+                                  : (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
+        }
+#pragma unroll
+        for (int mb = 0; mb < MBW; ++mb) {
+          const int row = orow[mb];
+#pragma unroll
+          for (int i = 0; i < NBW; ++i) {
+            const int c = (cg * NBW + i) * 16 + 4 * g;
+            f32x4 v = acc[mb][i];
+            if (scale) v = v * sc[i] + sh[i];
+            if (residual) v += rsd[mb][i];
+            if (relu) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.0f ? v[j] : 0.0f;
+            }
+            if (row >= 0) *reinterpret_cast<f32x4 *>(out + (size_t)row * COUT + c) = v;
+          }
+        }
+      }
+      if ((fl & 8) && tid < kHdrInts && cj + 2 < cnt) s_hdr[((cj + 2) % 3) * kHdrInts + tid] = hreg;
+      // end of the phase: this wave's share of the rows of phase q+1 has landed (vmcnt counts in
+      // order), LDS writes are done, then the barrier -- no fence, the younger DMA stays in flight
+      __builtin_amdgcn_s_waitcnt((kWaitN & 15) | ((kWaitN >> 4) << 14) | (7 << 4) | (0 << 8));
+      __builtin_amdgcn_s_barrier();
+    };
+    do {
+      phase(std::integral_constant<int, 0>{});
+      phase(std::integral_constant<int, 1>{});
+      phase(std::integral_constant<int, 2>{});
+    } while (((iA | iB | iC | iD) >> 13) & 1);
   }
 }
 
@@ -632,6 +891,40 @@ int launch_ordered(const OrdArgs &a) {
   return SF_OK;
 }
 
+bool env_dma() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("SF_ORD_DMA");
+    v = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  return v == 1;
+}
+
+template <int CIN, int COUT, int CG, int WAVES, int MINB>
+int launch_dma(const OrdArgs &a) {
+  auto kern = conv_f32_dma_kernel<CIN, COUT, CG, WAVES, MINB>;
+  static int slots = 0;          // resident workgroups on the device
+  if (slots == 0) {
+    int dev = 0, cus = 256, per_cu = 1;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, WAVES * 64, 0) != hipSuccess ||
+        per_cu < 1)
+      per_cu = 1;
+    slots = cus * per_cu;
+  }
+  const int tiles = plan_tiles(a.n_out_bound);
+  const int grid = tiles < slots ? tiles : slots;
+  sf_note_kernel("conv_f32_dma_kernel<%d, %d, %d, %d, %d>", CIN, COUT, CG, WAVES, MINB);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), 0, a.st, a.feat, a.feat_bytes,
+                     plan_view(a.plan, a.n_out_bound), a.K, a.k_first,
+                     reinterpret_cast<const f32x4 *>(a.wpk), a.scale, a.shift, a.residual, a.relu,
+                     a.out, a.n_out_dev, a.n_out_bound);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
 // Wave grid per shape: the column groups CG divide COUT/16; 8 waves where a wave's filter
 // registers (2 x NBW x CIN/16 float4) would otherwise not fit.
 template <int CIN>
@@ -640,11 +933,19 @@ int dispatch_ordered(int cout, const OrdArgs &a) {
     case 16: return launch_ordered<CIN, 16, 1, 4, 2>(a);
     case 32: return launch_ordered<CIN, 32, 2, 4, 2>(a);
     // (one filter set everywhere it was measured: 64 -> 64 141 vs 143 us; 3 workgroups per CU spill)
-    case 64: return launch_ordered<CIN, 64, 4, 4, 2, 1>(a);
+    // SF_ORD_DMA=0 keeps the register-staged kernel (A/B switch; both are tested)
+    case 64:
+      if constexpr (CIN == 64) {
+        if (env_dma()) return launch_dma<CIN, 64, 4, 4, 3>(a);      // 137 vs 141 us
+      }
+      return launch_ordered<CIN, 64, 4, 4, 2, 1>(a);
     case 128:
       // (one filter set: 200 instead of 230 VGPRs, 194 vs 200 us; four waves with two column
       // blocks each spill at 256)
-      if constexpr (CIN >= 128) return launch_ordered<CIN, 128, 8, 8, 1, 1>(a);
+      if constexpr (CIN >= 128) {
+        if (env_dma()) return launch_dma<CIN, 128, 8, 8, 1>(a);     // 187 vs 192 us
+        return launch_ordered<CIN, 128, 8, 8, 1, 1>(a);
+      }
       else return launch_ordered<CIN, 128, 4, 4, 2>(a);
   }
   sf_set_error("unsupported cout=%d (16, 32, 64 or 128)", cout);

@@ -30,5 +30,5 @@ with torch.no_grad():
     bb.enqueue(f); torch.cuda.synchronize()
 for cin, cout, v in res:
     w = max(v[7], 1); ph = max(v[4], 1)
-    print('%3dx%3d waves=%5d cyc/wave=%8.0f phases/wave=%5.1f (mult %.1f) | per phase: issue %5.0f  mma %5.0f  epi %5.0f  barrier %5.0f  sum %5.0f' % (
-        cin, cout, w, v[6] / w, v[4] / w, v[5] / w, v[0] / ph, v[1] / ph, v[2] / ph, v[3] / ph, v[:4].sum() / ph))
+    print('%3dx%3d waves=%5d cyc/wave=%8.0f phases/wave=%5.1f (mult %.1f) | per phase: issue %5.0f  mma %5.0f  epi %5.0f  barrier %5.0f  sum %5.0f | clock %4.0f MHz' % (
+        cin, cout, w, v[6] / w, v[4] / w, v[5] / w, v[0] / ph, v[1] / ph, v[2] / ph, v[3] / ph, v[:4].sum() / ph, v[6] / max(v[8], 1) * 100))
