@@ -602,8 +602,7 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, unsigned ch
 // one buffer from waiting for the DMA into another; the only wait for the DMA is the hand-counted
 // s_waitcnt vmcnt(N) in front of the raw s_barrier that ends a phase (a __syncthreads() there
 // would drain every DMA in flight): N = the memory operations a wave issues after the DMA of phase
-// q+1 (issued one phase ago) = its index loads and filter loads of that phase and everything of this
-// one.  Conditional extras (tile start / end) only make the wait stronger.
+// q+1 (issued one phase ago).  Conditional extras (tile start / end) only make the wait stronger.
 template <int CIN, int COUT, int CG, int WAVES, int MINB>
 __global__ void __launch_bounds__(WAVES * 64, MINB)
 conv_f32_dma_kernel(const float *__restrict__ feat, unsigned feat_bytes, PlanView pv, int K,
@@ -616,7 +615,9 @@ conv_f32_dma_kernel(const float *__restrict__ feat, unsigned feat_bytes, PlanVie
   constexpr int IPW = TM / RPI / WAVES;        // DMA instructions per wave and phase
   constexpr int NBL = NBW * T;                 // filter loads per wave and phase
   constexpr int kRun = 128, kLook = 3;
-  constexpr int kWaitN = 3 * IPW + 2 * NBL;    // see above
+  // memory operations a wave issues AFTER the DMA of phase q+1 (issued in phase q-1) until the end
+  // of phase q: last phase's filters (loaded behind its multiply), this phase's indices, DMA, filters
+  constexpr int kWaitN = 2 * IPW + 2 * NBL;
   static_assert(NB % CG == 0 && WAVES % CG == 0 && MBT % RG == 0 && CIN >= 64 && (TM / RPI) % WAVES == 0 &&
                     kWaitN < 64, "tile shape");
 
@@ -714,17 +715,21 @@ conv_f32_dma_kernel(const float *__restrict__ feat, unsigned feat_bytes, PlanVie
       unsigned char *const nxt2 = ph == 0 ? s_b2 : (ph == 1 ? s_b0 : s_b1);   // buffer of phase q+2
       tA = tB; iA = iB; tB = tC; iB = iC; tC = tD; iC = iD;
       next_desc(tD, iD);
-      // rows of phase q+2 -> LDS (indices loaded one phase ago), then the indices of phase q+3
+      // issue order (vmcnt retires in order): indices of phase q+3 first, then the rows of phase q+2
+      // -> LDS, so that next phase's wait for the indices does not retire the DMA early
       {
+        int inew[IPW];
+        const int *ip = pv.nbrs + (size_t)(iD & 31) * pv.s_stride + (size_t)tD * TM;
+#pragma unroll
+        for (int j = 0; j < IPW; ++j) inew[j] = ip[prow[j]];
         const bool live = (iC >> 9) & 1;
 #pragma unroll
         for (int j = 0; j < IPW; ++j) {
           const int src = live ? ireg[j] : -1;   // -1: out of range, zeros land in LDS, no fetch
           lds_dma16(rs, nxt2 + (wave * IPW + j) * 1024, (unsigned)src * ROWB + soff[j]);
         }
-        const int *ip = pv.nbrs + (size_t)(iD & 31) * pv.s_stride + (size_t)tD * TM;
 #pragma unroll
-        for (int j = 0; j < IPW; ++j) ireg[j] = ip[prow[j]];
+        for (int j = 0; j < IPW; ++j) ireg[j] = inew[j];
       }
       const int fl = iA >> 9;
       if (fl & 2) {            // first phase of a tile
@@ -782,7 +787,7 @@ conv_f32_dma_kernel(const float *__restrict__ feat, unsigned feat_bytes, PlanVie
             }
         }
       }
-      {   // the one filter set is free again: filters of phase q+1
+      {   // the filter registers are free again: filters of phase q+1
         const int k1 = iB & 31;
 #pragma unroll
         for (int i = 0; i < NBW; ++i)
@@ -936,14 +941,14 @@ int dispatch_ordered(int cout, const OrdArgs &a) {
     // SF_ORD_DMA=0 keeps the register-staged kernel (A/B switch; both are tested)
     case 64:
       if constexpr (CIN == 64) {
-        if (env_dma()) return launch_dma<CIN, 64, 4, 4, 3>(a);      // 137 vs 141 us
+        if (env_dma()) return launch_dma<CIN, 64, 4, 4, 3>(a);      // 136 vs 141 us
       }
       return launch_ordered<CIN, 64, 4, 4, 2, 1>(a);
     case 128:
       // (one filter set: 200 instead of 230 VGPRs, 194 vs 200 us; four waves with two column
       // blocks each spill at 256)
       if constexpr (CIN >= 128) {
-        if (env_dma()) return launch_dma<CIN, 128, 8, 8, 1>(a);     // 187 vs 192 us
+        if (env_dma()) return launch_dma<CIN, 128, 8, 8, 1>(a);     // 184 vs 192 us
         return launch_ordered<CIN, 128, 8, 8, 1, 1>(a);
       }
       else return launch_ordered<CIN, 128, 4, 4, 2>(a);
