@@ -281,6 +281,13 @@ SF_API int sf_sparse_conv_bf16(const void *features_in, int n_in_bound, int cin_
  * list): bench.py's roofline.kernel.  No reference counterpart (diagnostic). */
 SF_API const char *sf_last_conv_kernel(void);
 
+/* Diagnostic hooks exported by the library but NOT part of this interface (no declaration here
+ * on purpose): sf_debug_conv_profile, sf_debug_ordered_profile (a device buffer every convolution
+ * launch adds in-kernel cycle stamps to) and sf_debug_conv_row_order.  They set process-wide
+ * pointers read by every later launch on every stream: not thread- or stream-safe, used by
+ * tools/prof_conv.py / tools/prof_ordered.py / tools/ab_ordered.py only; NULL (the initial state)
+ * turns them off. */
+
 /* ---- the same convolution over mask-ordered rows (csrc/spconv_f32_ordered.hip) ---- */
 
 /* Workspace bytes of sf_row_order_by_mask for up to n_bound output rows. */
