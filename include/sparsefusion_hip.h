@@ -299,11 +299,11 @@ SF_API int sf_row_order_size(int n_bound);
 /* Builds the PLAN of a rulebook for sf_sparse_conv_f32_ordered in row_order (T = ceil(n_bound/64)):
  *   [0, n_bound)            the output rows sorted (stably) by their K-bit neighbour mask (bit k set
  *                           <=> nbr[k][row] >= 0); entries [*n_dev, n_bound) are -1 or unspecified
- *   [n_bound, +T)           the tile schedule: the 64-row tiles of the sorted rows by descending work
- *                           (number of (16-row block, offset) products), dealt to the persistent
- *                           workgroups of the convolution
+ *   [n_bound, +T)           the tile schedule: the 64-row tiles of the sorted rows by descending cost
+ *                           ((16-row block, offset) products + 3 per active offset), dealt to the
+ *                           persistent workgroups of the convolution
  *   + 32 T                  tile headers: [0] active offsets, [1..27] k | block mask << 8 ascending,
- *                           [28] work, [29] mask of the active offsets
+ *                           [28] cost, [29] mask of the active offsets
  *   + 27 * 64 T             the neighbour table permuted into the sorted order, column per offset
  * The buffer holds sf_row_order_size(n_bound) ints.  The sort is a hand-written 3-pass radix sort
  * bounded by the device-side row count (no library call, no host synchronisation); seven short

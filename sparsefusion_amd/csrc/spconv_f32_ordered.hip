@@ -251,28 +251,31 @@ tile_plan_kernel(const int *__restrict__ nbr, int nbr_stride, int K, const int *
     for (int d = 1; d < 64; d <<= 1) w += __shfl_xor(w, d, 64);
     if (lane == 0) {
       h[0] = __popcll(act);
-      h[28] = w;
+      // cost of the tile for the schedule: a phase costs about three block products of fixed work
+      // (descriptor, loads, barrier) besides its products; balancing products alone left the
+      // workgroups up to 1.5x apart in phases (tools: LPT simulation on the frame's real masks)
+      h[28] = w + 3 * __popcll(act);
       h[29] = (int)(unsigned)act;
     }
   }
 }
 
-// Tile schedule = tiles by descending work (counting sort over the <= 109 distinct weights, one
+// Tile schedule = tiles by descending cost (counting sort over the <= 190 distinct values, one
 // workgroup).  Dealt to the persistent workgroups in snake order it is a longest-processing-time
 // assignment: the heaviest tiles are spread first, the light ones level the tails.
 __global__ void __launch_bounds__(1024)
 tile_schedule_kernel(const int *__restrict__ hdr, const int *n_dev, int n_bound,
                      int *__restrict__ sched) {
-  __shared__ int s_cnt[128];
+  __shared__ int s_cnt[256];   // cost <= 108 + 3 * 27
   const int n = load_n(n_dev, n_bound);
   const int tiles = (n + kTileRows - 1) / kTileRows;
-  if (threadIdx.x < 128) s_cnt[threadIdx.x] = 0;
+  if (threadIdx.x < 256) s_cnt[threadIdx.x] = 0;
   __syncthreads();
-  for (int t = threadIdx.x; t < tiles; t += 1024) atomicAdd(&s_cnt[127 - hdr[(size_t)t * kHdrInts + 28]], 1);
+  for (int t = threadIdx.x; t < tiles; t += 1024) atomicAdd(&s_cnt[255 - hdr[(size_t)t * kHdrInts + 28]], 1);
   __syncthreads();
   if (threadIdx.x == 0) {
     int run = 0;
-    for (int i = 0; i < 128; ++i) {
+    for (int i = 0; i < 256; ++i) {
       const int c = s_cnt[i];
       s_cnt[i] = run;
       run += c;
@@ -281,7 +284,7 @@ tile_schedule_kernel(const int *__restrict__ hdr, const int *n_dev, int n_bound,
   __syncthreads();
   // equal weights keep no particular order (the schedule affects timing only, never results)
   for (int t = threadIdx.x; t < tiles; t += 1024)
-    sched[atomicAdd(&s_cnt[127 - hdr[(size_t)t * kHdrInts + 28]], 1)] = t;
+    sched[atomicAdd(&s_cnt[255 - hdr[(size_t)t * kHdrInts + 28]], 1)] = t;
 }
 
 struct PlanView {
