@@ -290,8 +290,13 @@ def main():
     ap.add_argument('--workload', default='nusc', choices=['nusc', 'waymo'])
     ap.add_argument('--frames', type=int, default=4, help='distinct synthetic frames per rank')
     ap.add_argument('--batch', type=int, default=1, help='frames per step (samples per batch)')
-    ap.add_argument('--streams', type=int, default=2,
-                    help='frames in flight per GPU (each on its own HIP stream and workspace)')
+    ap.add_argument('--streams', type=int, default=None,
+                    help='frames in flight per GPU, each with its own workspace (default 4 with the '
+                         'split pipeline, 2 with --single-graph)')
+    ap.add_argument('--single-graph', action='store_true',
+                    help="one HIP graph per frame with the coordinate phase forked inside it, one stream "
+                         "per frame in flight (round 1's loop; the hardware queues of the graph's "
+                         "branches are then the runtime's choice) instead of the split pipeline")
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
                     help="f32 = the headline config (BASELINE configs[1]); bf16 = configs[2] "
                          "(bf16 MFMA, fp32 accumulation; use with --batch 8)")
@@ -329,6 +334,9 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    split = not (args.single_graph or args.no_graph)
+    if args.streams is None:
+        args.streams = 4 if split else 2
     gen = synth.nuscenes_frame if args.workload == 'nusc' else synth.waymo_frame
     B = args.batch
     # weak scaling: a stream of world*frames*B frames dealt round-robin, rank r gets r, r+world, ...
@@ -344,18 +352,33 @@ def main():
                                   voxel_encoder=bb.vfe, bev_backbone=bb.bev_backbone, neck=bb.neck,
                                   strided_growth=args.strided_growth)
                     for _ in range(args.streams - 1)]
-    streams = [torch.cuda.Stream(device=dev) for _ in lanes]
+    if split:
+        # front + narrow layers of frame i on light[i % 2], the wide layers of every frame on one
+        # stream; the three streams on hardware queues of their own (LidarBackbone.capture_split)
+        from sparsefusion_amd.streams import concurrent_streams
+        (light0, light1, wide_st), n_queues = concurrent_streams(dev, 3)
+        streams = [wide_st for _ in lanes]
+    else:
+        n_queues = None
+        streams = [torch.cuda.Stream(device=dev) for _ in lanes]
     frames = [[torch.from_numpy(host_frames[f * B + b]).to(dev) for b in range(B)]
               for f in range(args.frames)]
     vf = None
     torch.cuda.synchronize()
 
+    split_frames = []  # split pipeline: per lane, the captured frames
+    wide_events = []   # split pipeline: (start, end) events around the wide-layer graph of every frame
     with torch.no_grad():
         steps = []   # steps[i] = (stream, callable): frame i % frames on lane i % streams
         for li, (lane, st) in enumerate(zip(lanes, streams)):
             with torch.cuda.stream(st):
                 if args.no_graph:
                     fns = [(lambda f=f, lane=lane: lane.enqueue(f, vf)) for f in frames]
+                elif split:
+                    light = (light0, light1)[li % 2]
+                    sfs = [lane.capture_split(f, [light, light, wide_st], voxel_features=vf) for f in frames]
+                    split_frames.append(sfs)
+                    fns = [(lambda sf=sf: sf.replay(timed=wide_events)) for sf in sfs]
                 else:
                     fns = [lane.capture(f, vf).replay for f in frames]
             steps.append((st, fns))
@@ -372,6 +395,7 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        wide_events.clear()
         t0 = time.perf_counter()
         for i in range(args.steps):
             run(i)
@@ -381,6 +405,23 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         elapsed = sharding.max_over_ranks(elapsed, dev)   # the only cross-rank traffic
+
+        # wide-layer graph: mean duration inside the running pipeline (the events of the timed region)
+        # and alone (one frame at a time on lane 0).  The per-layer timing below has the GPU to
+        # itself; in the pipeline the front and narrow kernels of the next frames run beside the wide
+        # layers, so their launches in the TIMED REGION last `wide_slowdown` times longer.
+        wide_slowdown, wide_ms = None, None
+        if split and rank == 0 and wide_events:
+            in_pipe = float(np.mean([a.elapsed_time(b) for a, b in wide_events]))
+            alone = []
+            for _ in range(3):
+                for sf in split_frames[0]:
+                    sf.replay(timed=alone)
+            torch.cuda.synchronize()
+            alone_ms = float(np.mean([a.elapsed_time(b) for a, b in alone[len(steps[0][1]):]]))
+            wide_slowdown = in_pipe / alone_ms
+            wide_ms = (in_pipe, alone_ms)
+        wide_events.clear()
 
         # ---- roofline of the dominant conv kernel (rank 0), outside the timed region -------
         roofline, detail = None, None
@@ -398,6 +439,8 @@ def main():
                 same launches read 230 us instead of 175 because they share the CUs)."""
                 for _ in range(nb):
                     steps[0][1][fi]()
+                if split:   # the replays run on the pipeline's streams: the timed frame follows them
+                    torch.cuda.current_stream(dev).wait_event(bb._last_segment_done)
 
             ms, work, counts, knames = None, None, None, None
             for fi, fr in enumerate(frames):
@@ -437,7 +480,11 @@ def main():
                 w['ms'] = float(t)
             dom = max(groups, key=lambda k: groups[k]['ms'])
             gd = groups[dom]
-            avg_s = gd['ms'] / gd['launches'] * 1e-3
+            alone_s = gd['ms'] / gd['launches'] * 1e-3     # launch duration with the GPU to itself
+            # duration of the same launches in the TIMED REGION: the wide-layer graph they are part
+            # of takes `wide_slowdown` times longer inside the pipeline than alone (events above)
+            scaled = wide_slowdown is not None and dom[0] >= 64
+            avg_s = alone_s * (wide_slowdown if scaled else 1.0)
             fl, by = gd['flops'] / gd['launches'], gd['bytes'] / gd['launches']
             peak_mfma = PEAK_BF16_MFMA_TFLOPS if dom[2] else PEAK_F32_MFMA_TFLOPS
             t_mfma, t_hbm = fl / (peak_mfma * 1e12), by / (PEAK_HBM_GBS * 1e9)
@@ -458,6 +505,11 @@ def main():
             roofline['traffic'], roofline['traffic_source'] = measured_traffic(heavy['kernel'], dom[2])
             roofline['launches_per_frame'] = gd['launches']
             roofline['avg_launch_us'] = round(avg_s * 1e6, 2)
+            roofline['avg_launch_us_alone'] = round(alone_s * 1e6, 2)
+            roofline['frac_alone'] = round(roofline['frac'] * avg_s / alone_s, 4)
+            if wide_ms is not None:
+                roofline['wide_graph_ms'] = {'in_pipeline': round(wide_ms[0], 4), 'alone': round(wide_ms[1], 4),
+                                             'applied_to_launch': bool(scaled)}
             roofline['algorithmic_flops_per_launch'] = fl
             roofline['algorithmic_bytes_per_launch'] = by
             tot_fl, tot_by = sum(w['flops'] for w in work), sum(w['bytes'] for w in work)
@@ -509,7 +561,10 @@ def main():
                        'points_per_frame': int(np.mean([p.shape[0] for p in host_frames])),
                        'voxels_frame0': detail['counts'][0] if detail else None,
                        'bev_backbone': 'SECOND + SECONDFPN (fp32) on the BEV map' if args.second else None,
-                       'hip_graph': not args.no_graph, 'frames_in_flight': args.streams, 'sharding': 'frames by rank, no collective'},
+                       'hip_graph': not args.no_graph, 'frames_in_flight': args.streams,
+                       'pipeline': ('split: front + narrow layers on 2 streams by frame parity, wide layers '
+                                    f'on 1, {n_queues} hardware queues' if split else
+                                    'one graph per frame, coordinate phase forked inside'), 'sharding': 'frames by rank, no collective'},
             'roofline': roofline,
             'verified': {'batches_checked': verified, 'rechecked_on_another_rank': len(recheck),
                          'frame0_rulebook_sha256': merged[expected[0]][0][:16],

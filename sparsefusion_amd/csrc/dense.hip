@@ -6,7 +6,10 @@
 // channel), each into a different channel plane) made the L2 fetch every line it touched: measured
 // 180 MB fetched to write 33 MB.  Instead the map is written output-stationary:
 //   1. the c = 0 planes of `out` (contiguous, D*H*W floats per sample) serve as a temporary cell ->
-//      row map: zero them, then every row writes row+1 (as bits) at its own cell;
+//      row map: zero them (a KERNEL, not hipMemsetAsync: a memset node between the kernel nodes of
+//      a captured linear graph was not ordered with them on ROCm 7.2 -- replays left marks of the
+//      previous frame in the map, tools/split_check.py), then every row writes row+1 (as bits) at
+//      its own cell;
 //   2. a workgroup owns 64 consecutive x of one (b, z, y) line: it reads the 64 map entries, stages
 //      the active rows through LDS (coalesced 16-byte row reads) and writes every channel plane
 //      with full 256-byte wave stores -- zeros included, so there is no separate zero fill, and
@@ -14,6 +17,15 @@
 #include "sf_common.h"
 
 namespace {
+
+__global__ void dense_zero_kernel(float *__restrict__ out, int C, int B, int D, size_t plane) {
+  const size_t per = (size_t)D * plane, total = per * B;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = i / per;
+    out[b * C * per + (i - b * per)] = 0.0f;
+  }
+}
 
 __global__ void dense_mark_kernel(const int *__restrict__ idx, const int *n_dev, int n_bound, int C,
                                   int B, int D, int H, int W, float *__restrict__ out) {
@@ -30,11 +42,13 @@ __global__ void dense_mark_kernel(const int *__restrict__ idx, const int *n_dev,
 
 template <int CT>  // channels staged per pass (C is processed in passes of CT)
 __global__ void __launch_bounds__(256)
-dense_write_kernel(const float *__restrict__ feat, int C, int B, int D, int H, int W,
-                   float *__restrict__ out) {
+dense_write_kernel(const float *__restrict__ feat, const int *n_dev, int n_bound, int C, int B, int D,
+                   int H, int W, float *__restrict__ out) {
   __shared__ float tile[64][CT + 1];
   __shared__ int rows[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int n = n_dev ? *n_dev : n_bound;
+  if (n > n_bound) n = n_bound;
   const int xt = (W + 63) / 64;
   const size_t plane = (size_t)H * W;
   const long long lines = (long long)B * D * H * xt;
@@ -47,7 +61,12 @@ dense_write_kernel(const float *__restrict__ feat, int C, int B, int D, int H, i
     const size_t cell = (size_t)y * W + x0;
     float *__restrict__ ob = out + ((size_t)b * C * D + z) * plane + cell;  // channel 0 of the line
     __syncthreads();  // previous line's tile / rows are consumed
-    if (tid < 64) rows[tid] = (x0 + tid < W) ? reinterpret_cast<const int *>(ob)[tid] - 1 : -1;
+    if (tid < 64) {
+      // a map entry is row + 1 of THIS frame or 0; anything else (it cannot be, but a stray value
+      // would index far outside `feat`) counts as empty
+      const int r = (x0 + tid < W) ? reinterpret_cast<const int *>(ob)[tid] - 1 : -1;
+      rows[tid] = (r >= 0 && r < n) ? r : -1;
+    }
     for (int c0 = C - (C % CT ? C % CT : CT); c0 >= 0; c0 -= CT) {  // channel 0 (the map) goes last
       const int cn = (C - c0 < CT) ? C - c0 : CT;
       __syncthreads();
@@ -76,9 +95,10 @@ extern "C" int sf_dense_bev(const float *features, const int *indices, const int
   SF_CHECK_ARG(out, "out is NULL");
   SF_CHECK_ARG(n_bound == 0 || (features && indices), "features / indices is NULL");
   const size_t plane = (size_t)H * W;
-  for (int b = 0; b < batch; ++b)  // the c = 0 planes: the temporary cell -> row map
-    SF_CHECK_HIP(hipMemsetAsync(out + (size_t)b * channels * D * plane, 0,
-                                (size_t)D * plane * sizeof(float), st));
+  // the c = 0 planes: the temporary cell -> row map
+  hipLaunchKernelGGL(dense_zero_kernel, dim3(sf_grid((long long)batch * D * plane, 256)), dim3(256), 0,
+                     st, out, channels, batch, D, plane);
+  SF_CHECK_LAUNCH();
   if (n_bound > 0) {
     hipLaunchKernelGGL(dense_mark_kernel, dim3(sf_grid(n_bound, 256)), dim3(256), 0, st, indices,
                        n_dev, n_bound, channels, batch, D, H, W, out);
@@ -86,8 +106,8 @@ extern "C" int sf_dense_bev(const float *features, const int *indices, const int
   }
   const long long lines = (long long)batch * D * H * ((W + 63) / 64);
   const int grid = (int)(lines < 8192 ? lines : 8192);
-  hipLaunchKernelGGL((dense_write_kernel<128>), dim3(grid), dim3(256), 0, st, features, channels,
-                     batch, D, H, W, out);
+  hipLaunchKernelGGL((dense_write_kernel<128>), dim3(grid), dim3(256), 0, st, features, n_dev, n_bound,
+                     channels, batch, D, H, W, out);
   SF_CHECK_LAUNCH();
   return SF_OK;
 }

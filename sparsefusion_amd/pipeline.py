@@ -28,6 +28,43 @@ class _Layer:
                  'shift', 'in_buf', 'out_buf', 'bf16', 'out_dtype', 'ordered')
 
 
+class _SplitFrame:
+    """One batch captured as a chain of linear graphs (LidarBackbone.capture_split), segment i on
+    streams[i].  replay() launches them in order, each waiting for the event of the one before;
+    the first waits until the last segment of this object's PREVIOUS batch is done (its buffers).
+
+    The events are plain torch events (device-scope release at the record): an event created with
+    hipEventDisableSystemFence carries NO cache release, and a consumer on another hardware queue
+    -- other XCDs, other L2s -- then reads stale lines of the previous frame: measured as an
+    illegal address in the wide layers (a plan half old, half new) on the small test frames."""
+
+    def __init__(self, owner, graphs, streams):
+        self.owner, self.graphs, self.streams = owner, graphs, streams
+        self.events = [torch.cuda.Event() for _ in graphs]
+
+    def replay(self, timed=None):
+        """timed: a list; a (start, end) pair of timing events around the LAST segment is appended
+        (bench.py: duration of the wide layers inside the running pipeline)."""
+        o = self.owner
+        prev = o._last_segment_done
+        last = len(self.graphs) - 1
+        for i, (g, st, ev) in enumerate(zip(self.graphs, self.streams, self.events)):
+            if prev is not None:
+                st.wait_event(prev)
+            with torch.cuda.stream(st):
+                if timed is not None and i == last:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(st)
+                    g.replay()
+                    e1.record(st)
+                    timed.append((e0, e1))
+                else:
+                    g.replay()
+                ev.record(st)
+            prev = ev
+        o._last_segment_done = prev
+
+
 def _flatten_encoder(enc):
     """SparseEncoder module tree -> [(conv, bn, relu, identity_role)] in forward
     order (sparse_encoder.py:112-121, sparse_block.py:116-139).  Only the post-activation
@@ -111,6 +148,7 @@ class LidarBackbone:
         self.materialize = materialize_voxels
         self.overlap = bool(overlap)      # coordinate phase on a second stream
         self.side_stream = torch.cuda.Stream(device=self.dev) if self.overlap else None
+        self._last_segment_done = None   # capture_split: event at the end of this object's last batch
         self.enc = encoder
         self.in_channels = encoder.in_channels
         self.F = None  # point feature count, fixed at first call
@@ -279,6 +317,34 @@ class LidarBackbone:
         voxel_features: optional (>= B*max_voxels, in_channels) f32 tensor used as the encoder
         input instead of the fused per-voxel mean (configs whose voxel encoder is a learned VFE,
         e.g. the Waymo config's 64-channel HardVFE, which is not part of this path)."""
+        dev = self.dev
+        self._front(points_list, voxel_features)
+        # ---- coordinate phase: on its own stream, forked after the voxelizer ---------------
+        # The hash / neighbour-table kernels are latency bound and need no LDS: they run in the
+        # shadow of the MFMA-bound convolutions of the earlier stages.  Each rulebook records an
+        # event; the feature phase waits for it before the first layer that uses the rulebook
+        # (under graph capture these become fork / join edges of the graph).
+        main = torch.cuda.current_stream(dev)
+        fork = self.overlap and len(self.rulebooks) > 1
+        side = self.side_stream if fork else main
+        if fork:
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+        rb_ready = {}
+        for ri in range(1, len(self.rulebooks)):
+            self._rulebook(ri, side.cuda_stream)
+            if fork:
+                e = torch.cuda.Event()
+                e.record(side)
+                rb_ready[ri] = e
+        self._feature_input(voxel_features)
+        self._features(0, len(self.layers), rb_ready)
+        return self._dense_and_after()
+
+    def _front(self, points_list, voxel_features):
+        """Voxelizer (+ mean, + batch index), hash of the voxel coordinates and the FIRST rulebook
+        (it feeds the very first layer), all on the current stream."""
         L, dev = self.L, self.dev
         st = _lib.stream(dev)
         chk = _lib.check
@@ -298,7 +364,7 @@ class LidarBackbone:
             raise RuntimeError(f'encoder wants {self.in_channels} input channels but points have '
                                f'{self.F} features: pass voxel_features')
         nf = min(self.in_channels, self.F)
-        # ---- voxelize (+ mean, + batch index), samples append behind each other ----------
+        # samples append behind each other
         for b, pts in enumerate(points_list):
             if pts.shape[0] > self.max_points_in or pts.shape[1] != self.F:
                 raise RuntimeError('point cloud larger than max_points or feature count changed')
@@ -310,53 +376,43 @@ class LidarBackbone:
                 b, self.num_points.data_ptr(),
                 self.mean.data_ptr() if self.vfe is None else None, nf, self.cin_pad, c0,
                 s0['bound'], ovf, None, self.vox_ws.data_ptr(), self.vox_ws_bytes, st))
-        # ---- coordinate phase: on its own stream, forked after the voxelizer ---------------
-        # The hash / neighbour-table kernels are latency bound and need no LDS: they run in the
-        # shadow of the MFMA-bound convolutions of the earlier stages.  Each rulebook records an
-        # event; the feature phase waits for it before the first layer that uses the rulebook
-        # (under graph capture these become fork / join edges of the graph).
-        main = torch.cuda.current_stream(dev)
-        side = self.side_stream if self.overlap else main
         chk(L.sf_hash_build(s0['indices'].data_ptr(), c0, s0['bound'], _lib.i3(s0['shape']),
                             self.B, s0['keys'].data_ptr(), s0['vals'].data_ptr(), s0['cap'], ovf,
                             st))
-        fork = self.overlap and len(self.rulebooks) > 1
-        if fork:
-            ev = torch.cuda.Event()
-            ev.record(main)
-            side.wait_event(ev)
-        rb_ready = {}
-        for ri, rb in enumerate(self.rulebooks):
-            src, dst = self.sets[rb['src']], self.sets[rb['dst']]
-            n_src, n_dst = c0 + 4 * rb['src'], c0 + 4 * rb['dst']
-            # the first rulebook feeds the very first layer: it stays on the main stream
-            ss = side.cuda_stream if (fork and ri > 0) else st
-            if not rb['subm']:
-                # output set + neighbour table from the input side (one probe per pair)
-                chk(L.sf_strided_rulebook(
-                    src['indices'].data_ptr(), n_src, src['bound'], self.B, _lib.i3(dst['shape']),
-                    _lib.i3(rb['ks']), _lib.i3(rb['st']), _lib.i3(rb['pd']), dst['keys'].data_ptr(),
-                    dst['vals'].data_ptr(), dst['cap'], dst['indices'].data_ptr(), dst['bound'],
-                    n_dst, ovf, rb['nbr'].data_ptr(), rb['stride'], self.rb_ws.data_ptr(),
-                    self.rb_ws_bytes, ss))
-                self._row_order(rb, n_dst, dst['bound'], ss)
-                if fork and ri > 0:
-                    e = torch.cuda.Event()
-                    e.record(side)
-                    rb_ready[ri] = e
-                continue
+        self._rulebook(0, st)
+
+    def _rulebook(self, ri, ss):
+        """Rulebook `ri` (and its mask order, where a layer uses one) on the raw stream `ss`."""
+        L, chk = self.L, _lib.check
+        rb = self.rulebooks[ri]
+        c0 = self.counts.data_ptr()
+        ovf = c0 + 4 * len(self.sets)
+        src, dst = self.sets[rb['src']], self.sets[rb['dst']]
+        n_src, n_dst = c0 + 4 * rb['src'], c0 + 4 * rb['dst']
+        if not rb['subm']:
+            # output set + neighbour table from the input side (one probe per pair)
+            chk(L.sf_strided_rulebook(
+                src['indices'].data_ptr(), n_src, src['bound'], self.B, _lib.i3(dst['shape']),
+                _lib.i3(rb['ks']), _lib.i3(rb['st']), _lib.i3(rb['pd']), dst['keys'].data_ptr(),
+                dst['vals'].data_ptr(), dst['cap'], dst['indices'].data_ptr(), dst['bound'],
+                n_dst, ovf, rb['nbr'].data_ptr(), rb['stride'], self.rb_ws.data_ptr(),
+                self.rb_ws_bytes, ss))
+        else:
             chk(L.sf_neighbor_table(
                 dst['indices'].data_ptr(), n_dst, dst['bound'], self.B, _lib.i3(src['shape']),
                 _lib.i3(rb['ks']), _lib.i3(rb['st']), _lib.i3(rb['pd']), src['keys'].data_ptr(),
                 src['vals'].data_ptr(), src['cap'], 1 if rb['subm'] else 0, rb['nbr'].data_ptr(),
                 rb['stride'], ss))
-            self._row_order(rb, n_dst, dst['bound'], ss)
-            if fork and ri > 0:
-                e = torch.cuda.Event()
-                e.record(side)
-                rb_ready[ri] = e
-        waited = set()
-        # ---- feature phase -----------------------------------------------------------------
+        self._row_order(rb, n_dst, dst['bound'], ss)
+
+    def _feature_input(self, voxel_features):
+        """Encoder input of this batch: the fused mean, the HardVFE layers' output, or the caller's
+        voxel_features.  Leaves the running (x, channels, block input) state for _features."""
+        L, dev = self.L, self.dev
+        st = _lib.stream(dev)
+        chk = _lib.check
+        c0 = self.counts.data_ptr()
+        s0 = self.sets[0]
         x, x_ch = self.mean, self.cin_pad
         if self.vfe is not None and voxel_features is None:
             v = self.vfe
@@ -382,8 +438,20 @@ class LidarBackbone:
                 raise RuntimeError('voxel_features must be (>= B*max_voxels, padded in_channels)')
             _lib.ptr(voxel_features)
             x = voxel_features
-        block_in = None
-        for li, lay in enumerate(self.layers):
+        self._fstate = (x, x_ch, None)
+
+    def _features(self, lo, hi, rb_ready):
+        """Layers lo..hi-1 on the current stream; waits for the event of a rulebook in `rb_ready`
+        before the first layer that uses it."""
+        L, dev = self.L, self.dev
+        st = _lib.stream(dev)
+        chk = _lib.check
+        main = torch.cuda.current_stream(dev)
+        c0 = self.counts.data_ptr()
+        x, x_ch, block_in = self._fstate
+        waited = set()
+        for li in range(lo, hi):
+            lay = self.layers[li]
             rb = lay.rb
             bufs = self.fbufs[(rb['dst'], lay.cout, lay.out_dtype)]
             busy = {x.data_ptr()}
@@ -430,7 +498,16 @@ class LidarBackbone:
                                        self.cast0.shape[1], c0 + 4 * rb['dst'],
                                        self.sets[rb['dst']]['bound'], st))
                 x, x_ch = self.cast0, self.cast0.shape[1]
-        # ---- dense BEV ---------------------------------------------------------------------
+        self._fstate = (x, x_ch, block_in)
+
+    def _dense_and_after(self):
+        """Dense BEV map of the last layer's rows, then the optional SECOND / FPN / height maps."""
+        L, dev = self.L, self.dev
+        st = _lib.stream(dev)
+        chk = _lib.check
+        c0 = self.counts.data_ptr()
+        s0 = self.sets[0]
+        x = self._fstate[0]
         o = self.sets[self.out_set]
         D, H, W = o['shape']
         chk(L.sf_dense_bev(x.data_ptr(), o['indices'].data_ptr(), c0 + 4 * self.out_set, o['bound'],
@@ -493,3 +570,65 @@ class LidarBackbone:
         with torch.cuda.graph(g):
             self.enqueue(points_list, voxel_features)
         return g
+
+    def capture_split(self, points_list, streams, cut=None, voxel_features=None):
+        """The same batch as a CHAIN of linear HIP graphs, each on a stream the caller names,
+        instead of one graph with forks inside.  Segments: the front (voxelizer, hash, every
+        rulebook and mask order), then the layer ranges [0, cut), [cut, end) (+ the dense map and
+        what follows it); `cut` may also be a list of ascending layer indices (more ranges).
+        streams[i] runs segment i; consecutive segments on the same stream become one graph.  cut
+        defaults to the first layer with >= 64 input channels: in front of it the kernels are bound
+        by load latency, behind it by the matrix pipe.  Returns an object with .replay().
+
+        Why (tools/queue_probe.py): the same captured frames measured 2.02 / 2.17 /
+        2.24 / 2.46 ms per frame with two frames in flight, depending only on which hardware queue
+        (GPU_MAX_HW_QUEUES = 4) the HIP runtime had given the branches of each graph.  With plain
+        streams the caller decides.  The layout that reproduces the best case by construction: the
+        wide layers of ALL frames in flight on ONE stream (one behind the other, each with the
+        whole GPU), front + narrow layers on one of TWO other streams by frame parity, four
+        LidarBackbone objects in flight (`streams.concurrent_streams` finds streams that do not
+        share a queue): the latency-bound kernels of the next two frames fill the matrix-bound
+        kernels' shadow and are never in front of them in a queue."""
+        dev = self.dev
+        nl = len(self.layers)
+        if cut is None:
+            cut = next((i for i, lay in enumerate(self.layers) if lay.cin >= 64), nl // 2)
+        cuts = [cut] if isinstance(cut, int) else list(cut)
+        edges = [0] + cuts + [nl]
+        if any(b <= a for a, b in zip(edges, edges[1:])):
+            raise ValueError(f'cuts {cuts} must ascend strictly inside the {nl} layers')
+        if len(streams) != len(edges):
+            raise ValueError(f'{len(edges)} segments (front + {len(edges) - 1} layer ranges) need as many streams')
+        torch.cuda.synchronize(dev)      # earlier batches of this object may still be in flight
+        self.enqueue(points_list, voxel_features)
+        torch.cuda.synchronize(dev)
+
+        def front():
+            self._front(points_list, voxel_features)
+            ss = _lib.stream(dev)
+            for ri in range(1, len(self.rulebooks)):
+                self._rulebook(ri, ss)
+
+        def layers(lo, hi):
+            def fn():
+                if lo == 0:
+                    self._feature_input(voxel_features)
+                self._features(lo, hi, {})
+                if hi == nl:
+                    self._dense_and_after()
+            return fn
+
+        fns = [front] + [layers(a, b) for a, b in zip(edges, edges[1:])]
+        graphs, gstreams, i = [], [], 0
+        while i < len(fns):
+            j = i + 1
+            while j < len(fns) and streams[j] is streams[i]:
+                j += 1
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for fn in fns[i:j]:
+                    fn()
+            graphs.append(g)
+            gstreams.append(streams[i])
+            i = j
+        return _SplitFrame(self, graphs, gstreams)

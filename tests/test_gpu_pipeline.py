@@ -69,6 +69,63 @@ def test_graph_replay_and_reuse_across_frames(dev, oracle):
             assert bb.results()['overflow'] == 0
 
 
+def test_split_pipeline_frames_in_flight(dev):
+    """capture_split: chains of linear graphs on caller-named streams, several frames in flight on
+    several LidarBackbone objects without a host sync in between; every frame must come out
+    bit-identical to the plain enqueue (same kernels, same order), also when an object is reused
+    while later frames are still running and when a smaller frame follows a larger one."""
+    from sparsefusion_amd.streams import concurrent_streams
+    enc, sd, cfg = make_encoder(dev, 5, 14)
+    (light0, light1, wide), nq = concurrent_streams(dev, 3)
+    assert 1 <= nq <= 3
+    print('STAGE streams', nq, flush=True)
+    sizes = [5000, 2000, 4200, 3100, 6000, 1500, 3600]
+    pts = [[to_dev(small_points(400 + i, n), dev)] for i, n in enumerate(sizes)]
+    ref = LidarBackbone(VL, enc, dev, max_points=8000, batch_size=1)
+    expect = []
+    with torch.no_grad():
+        for p in pts:
+            expect.append(ref(p).clone())
+            assert ref.results()['overflow'] == 0
+        print('STAGE ref done', flush=True)
+        lanes = [LidarBackbone(VL, enc, dev, max_points=8000, batch_size=1) for _ in range(3)]
+        frames = []
+        for i, p in enumerate(pts):
+            light = (light0, light1)[i % 2]
+            frames.append(lanes[i % 3].capture_split(p, [light, light, wide]))
+        torch.cuda.synchronize()
+        print('STAGE captured', flush=True)
+        for i, f in enumerate(frames[:3]):
+            f.replay()
+            torch.cuda.synchronize()
+            print('STAGE single replay', i, bool(torch.equal(lanes[i % 3].bev, expect[i])), flush=True)
+        for rnd in range(2):
+            # frames 0..6 back to back: lane i % 3 is reused every third frame without a sync
+            for f in frames:
+                f.replay()
+            torch.cuda.synchronize()
+            print('STAGE round', rnd, flush=True)
+            for i in (4, 5, 6):   # the last frame each object ran
+                assert torch.equal(lanes[i % 3].bev, expect[i]), (rnd, i)
+        # frame by frame with a sync: every frame, every object
+        for i, f in enumerate(frames):
+            f.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(lanes[i % 3].bev, expect[i]), i
+            assert lanes[i % 3].results()['overflow'] == 0
+        # other cuts / one stream for everything give the same numbers
+        f1 = lanes[0].capture_split(pts[0], [wide, wide, wide])
+        f2 = lanes[1].capture_split(pts[0], [light0, light1, wide, light1], cut=[3, 7])
+        for f, lane in ((f1, lanes[0]), (f2, lanes[1])):
+            f.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(lane.bev, expect[0])
+    with pytest.raises(ValueError):
+        lanes[0].capture_split(pts[0], [wide, wide])
+    with pytest.raises(ValueError):
+        lanes[0].capture_split(pts[0], [wide, wide, wide], cut=[5, 5])
+
+
 def test_voxel_cap_inside_pipeline(dev, oracle):
     enc, sd, cfg = make_encoder(dev, 5, 13)
     vl = dict(VL, max_voxels=(500, 800))   # cap triggers: the reference's break semantics
