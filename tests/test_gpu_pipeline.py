@@ -78,7 +78,6 @@ def test_split_pipeline_frames_in_flight(dev):
     enc, sd, cfg = make_encoder(dev, 5, 14)
     (light0, light1, wide), nq = concurrent_streams(dev, 3)
     assert 1 <= nq <= 3
-    print('STAGE streams', nq, flush=True)
     sizes = [5000, 2000, 4200, 3100, 6000, 1500, 3600]
     pts = [[to_dev(small_points(400 + i, n), dev)] for i, n in enumerate(sizes)]
     ref = LidarBackbone(VL, enc, dev, max_points=8000, batch_size=1)
@@ -87,24 +86,17 @@ def test_split_pipeline_frames_in_flight(dev):
         for p in pts:
             expect.append(ref(p).clone())
             assert ref.results()['overflow'] == 0
-        print('STAGE ref done', flush=True)
         lanes = [LidarBackbone(VL, enc, dev, max_points=8000, batch_size=1) for _ in range(3)]
         frames = []
         for i, p in enumerate(pts):
             light = (light0, light1)[i % 2]
             frames.append(lanes[i % 3].capture_split(p, [light, light, wide]))
         torch.cuda.synchronize()
-        print('STAGE captured', flush=True)
-        for i, f in enumerate(frames[:3]):
-            f.replay()
-            torch.cuda.synchronize()
-            print('STAGE single replay', i, bool(torch.equal(lanes[i % 3].bev, expect[i])), flush=True)
         for rnd in range(2):
             # frames 0..6 back to back: lane i % 3 is reused every third frame without a sync
             for f in frames:
                 f.replay()
             torch.cuda.synchronize()
-            print('STAGE round', rnd, flush=True)
             for i in (4, 5, 6):   # the last frame each object ran
                 assert torch.equal(lanes[i % 3].bev, expect[i]), (rnd, i)
         # frame by frame with a sync: every frame, every object
