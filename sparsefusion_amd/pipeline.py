@@ -592,7 +592,10 @@ class LidarBackbone:
         dev = self.dev
         nl = len(self.layers)
         if cut is None:
-            cut = next((i for i, lay in enumerate(self.layers) if lay.cin >= 64), nl // 2)
+            # (a 64-channel INPUT layer, as behind the Waymo config's HardVFE, is not the cut)
+            first_narrow = next((i for i, lay in enumerate(self.layers) if lay.cin < 64), nl)
+            cut = next((i for i, lay in enumerate(self.layers) if i > first_narrow and lay.cin >= 64),
+                       max(nl // 2, 1))
         cuts = [cut] if isinstance(cut, int) else list(cut)
         edges = [0] + cuts + [nl]
         if any(b <= a for a, b in zip(edges, edges[1:])):

@@ -177,3 +177,57 @@ def test_waymo_frame_fp32(dev, oracle):
     expect = oracle.sparse_encoder_forward(sd, feats, coors4, 1, ecfg['sparse_shape'], 64, **okw)
     assert expect.shape == (1, 256, 188, 188)
     assert_close(bev.cpu().numpy(), expect, 1e-4)
+
+
+def test_graph_replays_equal_eager_fullsize(dev):
+    """What bench.py times are graph REPLAYS: on nuScenes-shaped frames they must leave exactly the
+    buffers the eager enqueue leaves (rulebooks and BEV map, bit for bit) -- for the one-graph capture
+    and for the split pipeline with four objects in flight, with frames of different sizes
+    following each other on the same object.  (Round 2 found a replay-only fault this way: a memset
+    node inside a captured graph was not ordered with the kernel nodes around it.)"""
+    import hashlib
+    from sparsefusion_amd.streams import concurrent_streams
+    cfg = configs.NUSC
+    host = [synth.nuscenes_frame(i) for i in range(3)]
+    max_pts = max(p.shape[0] for p in host)
+    frames = [[to_dev(p, dev)] for p in host]
+
+    def digest(bb):
+        torch.cuda.synchronize()
+        c = bb.counts.tolist()
+        h = hashlib.sha256(np.asarray(c, np.int64).tobytes())
+        for rb in bb.rulebooks:
+            n = c[rb['dst']]
+            h.update(bb.sets[rb['dst']]['indices'][:n].cpu().numpy().tobytes())
+            h.update(rb['nbr'][:, :n].contiguous().cpu().numpy().tobytes())
+        h.update(bb.bev.cpu().numpy().tobytes())
+        return h.hexdigest()
+
+    ref, *_ = build(cfg, dev, 1, max_pts)
+    with torch.no_grad():
+        want = []
+        for f in frames:
+            ref(f)
+            assert ref.results()['overflow'] == 0
+            want.append(digest(ref))
+        assert len(set(want)) == len(want)
+        # one graph per frame (forks inside), replayed in an order that differs from the capture order
+        graphs = [ref.capture(f) for f in frames]
+        for fi in (1, 0, 2, 2, 0, 1):
+            graphs[fi].replay()
+            assert digest(ref) == want[fi], ('capture', fi)
+        del graphs
+        # split pipeline, bench.py's layout
+        (l0, l1, wide), _ = concurrent_streams(dev, 3)
+        lanes = [LidarBackbone(cfg['pts_voxel_layer'], ref.enc, dev, max_pts, batch_size=1)
+                 for _ in range(4)]
+        caps = [[lane.capture_split(f, [(l0, l1)[li % 2]] * 2 + [wide]) for f in frames]
+                for li, lane in enumerate(lanes)]
+        for rnd in range(2):
+            last = {}
+            for i in range(24):
+                li, fi = i % 4, (i * 2 + rnd + i // 4) % 3
+                caps[li][fi].replay()
+                last[li] = fi
+            for li, fi in last.items():
+                assert digest(lanes[li]) == want[fi], ('split', rnd, li, fi)
