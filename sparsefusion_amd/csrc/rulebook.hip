@@ -824,7 +824,7 @@ extern "C" int sf_export_indice_pairs(const int *nbr, int nbr_stride, int K, con
     sf_set_error("workspace too small: %zu < %zu bytes", workspace_bytes, need);
     return SF_ERR_WORKSPACE;
   }
-  SF_CHECK_HIP(hipMemsetAsync(indice_num, 0, sizeof(int) * K, st));
+  SF_FILL_U32(indice_num, K, 0u, st);
   if (n_in == 0) return SF_OK;
   SF_CHECK_ARG(nbr && indice_pairs, "nbr / indice_pairs is NULL");
   int *inv = (int *)workspace;

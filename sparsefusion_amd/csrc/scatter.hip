@@ -172,7 +172,7 @@ long long cells_of(const int *dims, int ndim) {
 extern "C" int sf_coors_max(const int *coors, int n, int ndim, int *max_dev, void *stream) {
   hipStream_t st = (hipStream_t)stream;
   SF_CHECK_ARG(n >= 0 && ndim >= 1 && ndim <= 4 && max_dev, "bad n / ndim / max_dev");
-  SF_CHECK_HIP(hipMemsetAsync(max_dev, 0xFF, sizeof(int) * ndim, st));  // -1
+  SF_FILL_U32(max_dev, ndim, 0xFFFFFFFFu, st);  // -1
   if (n == 0) return SF_OK;
   SF_CHECK_ARG(coors, "coors is NULL");
   hipLaunchKernelGGL(coors_max_kernel, dim3(sf_grid(n, 256)), dim3(256), 0, st, coors, n, ndim,
@@ -217,7 +217,7 @@ extern "C" int sf_dynamic_scatter(const float *feats, const int *coors, int n, i
   int *bsum = wprefix + words;
   const int3 d3 = make_int3(dims[0], ndim > 1 ? dims[1] : 1, ndim > 2 ? dims[2] : 1);
   const int d4 = ndim > 3 ? dims[3] : 1;
-  SF_CHECK_HIP(hipMemsetAsync(bitmap, 0, (size_t)words * 4, st));
+  SF_FILL_U32(bitmap, words, 0u, st);
   if (n > 0) {
     hipLaunchKernelGGL(ds_setbits_kernel, dim3(sf_grid(n, 256)), dim3(256), 0, st, coors, n, ndim,
                        d3, d4, bitmap);

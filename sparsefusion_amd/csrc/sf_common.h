@@ -45,6 +45,24 @@ static inline int sf_grid(long long items, int threads) {
   return (int)b;
 }
 
+// Fill `n` 32-bit words with `v`, as a KERNEL.  The library issues no hipMemset*: a memset node
+// between kernel nodes of a captured linear HIP graph was not ordered with them on ROCm 7.2 (replays
+// of sf_dense_bev kept marks of the previous frame), so every sequence of this
+// library captures as kernel nodes only.
+static __global__ void sf_fill_u32_kernel(uint32_t *__restrict__ p, size_t n, uint32_t v) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    p[i] = v;
+}
+#define SF_FILL_U32(ptr, n_words, value, st)                                                      \
+  do {                                                                                            \
+    if ((size_t)(n_words) > 0) {                                                                  \
+      hipLaunchKernelGGL(sf_fill_u32_kernel, dim3(sf_grid((long long)(n_words), 256)), dim3(256), \
+                         0, st, (uint32_t *)(ptr), (size_t)(n_words), (uint32_t)(value));         \
+      SF_CHECK_LAUNCH();                                                                          \
+    }                                                                                             \
+  } while (0)
+
 // ---------------------------------------------------------------- device side
 __device__ __forceinline__ uint32_t sf_hash32(uint32_t k) {
   // multiplicative (Fibonacci) hash followed by a xor-fold; capacity is a power of two
