@@ -597,9 +597,13 @@ class LidarBackbone:
             cut = next((i for i, lay in enumerate(self.layers) if i > first_narrow and lay.cin >= 64),
                        max(nl // 2, 1))
         cuts = [cut] if isinstance(cut, int) else list(cut)
-        edges = [0] + cuts + [nl]
+        # a last cut == number of layers gives the dense map (and what follows it) a segment of its own
+        tail = bool(cuts) and cuts[-1] == nl
+        edges = [0] + (cuts[:-1] if tail else cuts) + [nl]
         if any(b <= a for a, b in zip(edges, edges[1:])):
             raise ValueError(f'cuts {cuts} must ascend strictly inside the {nl} layers')
+        if tail:
+            edges.append(nl)
         if len(streams) != len(edges):
             raise ValueError(f'{len(edges)} segments (front + {len(edges) - 1} layer ranges) need as many streams')
         torch.cuda.synchronize(dev)      # earlier batches of this object may still be in flight
@@ -616,8 +620,9 @@ class LidarBackbone:
             def fn():
                 if lo == 0:
                     self._feature_input(voxel_features)
-                self._features(lo, hi, {})
-                if hi == nl:
+                if hi > lo:
+                    self._features(lo, hi, {})
+                if hi == nl and (lo == nl or not tail):
                     self._dense_and_after()
             return fn
 

@@ -39,13 +39,21 @@ def queue_classes(streams, cycles=4_000_000):
 
 
 def concurrent_streams(device, n, candidates=12):
-    """n streams of `device` on pairwise different hardware queues (fewer queues than n: the
-    streams of the classes found are handed out round-robin, so the caller still gets n streams
-    and the code runs, just with less overlap).  Returns (streams, number of distinct queues)."""
+    """n DISTINCT streams of `device`, on pairwise different hardware queues as far as the probe
+    finds that many (fewer: the rest are further streams of the pool, which then share a queue
+    with one of the others -- the code runs, with less overlap; a probe disturbed by another
+    process on the same GPU errs towards this side).  Returns (streams, distinct queues found)."""
     device = torch.device(device)
     with torch.cuda.device(device):
         pool = [torch.cuda.Stream(device=device) for _ in range(max(candidates, n))]
         classes = queue_classes(pool)
-    reps = [pool[c[0]] for c in classes]
-    picked = [reps[i % len(reps)] for i in range(n)]
-    return picked, min(len(reps), n)
+    picked = [pool[c[0]] for c in classes][:n]
+    found = len(picked)
+    depth = 1
+    while len(picked) < n:          # second, third ... member of every class
+        more = [pool[c[depth]] for c in classes if len(c) > depth]
+        if not more:
+            raise RuntimeError(f'{len(pool)} candidate streams cannot give {n} distinct ones')
+        picked += more[:n - len(picked)]
+        depth += 1
+    return picked, found

@@ -37,6 +37,8 @@ def main():
     ap.add_argument('--lanes', type=int, default=4)
     ap.add_argument('--pairs', action='store_true')
     ap.add_argument('--layouts', action='store_true')
+    ap.add_argument('--hide', action='store_true', help='light segments beside the wide layers: hidden share')
+    ap.add_argument('--tail', action='store_true', help='with --layouts: only the variants that move the tail of a frame')
     args = ap.parse_args()
     dev = torch.device('cuda', 0)
     torch.cuda.set_device(dev)
@@ -83,6 +85,38 @@ def main():
                       f'{"+".join(names[i] for i in sb) or "-":20s} {t:6.3f} ms per round', flush=True)
             del fa, fb
 
+        if args.hide:
+            # how much of each light segment hides behind the wide layers of another frame
+            cuts = [6, 10, 11]
+            segn = ['front', 'layers 0-5 (<=16 ch)', 'layers 6-9 (32->32)', 'layer 10 (32->64)', 'wide']
+            fa = lanes[0].capture_split(frames[1], [Q(0), Q(1), Q(2), Q(3), Q(0)], cut=cuts)
+            fb = lanes[1].capture_split(frames[2], [Q(0), Q(1), Q(2), Q(3), Q(0)], cut=cuts)
+            torch.cuda.synchronize()
+
+            def run_pair(sa, sb, n=80):
+                def go():
+                    for _ in range(n):
+                        if sa is not None:
+                            with torch.cuda.stream(Q(0)):
+                                fa.graphs[sa].replay()
+                        if sb is not None:
+                            with torch.cuda.stream(Q(1)):
+                                fb.graphs[sb].replay()
+                go()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                go()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / n * 1e3
+            tw = run_pair(None, 4)
+            print(f'wide layers alone {tw:.3f} ms', flush=True)
+            for sidx in range(4):
+                ts = run_pair(sidx, None)
+                tp = run_pair(sidx, 4)
+                print(f'{segn[sidx]:24s} alone {ts:.3f} ms, beside the wide layers of another frame {tp:.3f} ms: '
+                      f'{(ts + tw - tp) / ts * 100:5.1f} % hidden', flush=True)
+            del fa, fb
+
         if args.layouts:
             def timeit(nl, assign, cut):
                 steps = []
@@ -122,6 +156,17 @@ def main():
                 ('same, cut behind the first 64->64', 4, parity(4, (Q(3),)), 12),
                 ('same, 64- and 128-channel layers apart', 4, parity(4, (Q(3), Q(2))), [11, 16]),
             ]
+            def par_tail(nl, cutlist):
+                # the tail of every frame on the fourth queue (on a light stream it would queue up
+                # behind the front of a LATER frame: 2.27 ms)
+                return tuple((Q(i % 2), Q(i % 2), Q(3)) + (Q(2),) * (len(cutlist) - 1) for i in range(nl))
+            if args.tail:
+                tried = [('front+narrow by frame parity | wide', 4, parity(4, (Q(3),)), None),
+                         ('same, dense map on the fourth queue', 4, par_tail(4, [11, 21]), [11, 21]),
+                         ('same, conv_out + dense map on the fourth queue', 4, par_tail(4, [11, 20]), [11, 20]),
+                         ('same, dense map on the fourth queue', 5, par_tail(5, [11, 21]), [11, 21]),
+                         ('same, conv_out + dense map on the fourth queue', 5, par_tail(5, [11, 20]), [11, 20]),
+                         ('front+narrow by frame parity | wide', 4, parity(4, (Q(3),)), None)]
             for name, nl, a, cut in tried:
                 if nl > len(lanes):
                     continue

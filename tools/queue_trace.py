@@ -99,3 +99,44 @@ def timeline(trace, log, build, t_from_ms, t_len_ms):
 
 if __name__ == '__main__' and len(sys.argv) > 3:
     timeline(sys.argv[1], sys.argv[2], int(sys.argv[3]), float(sys.argv[4]), float(sys.argv[5]))
+
+
+def gaps(trace):
+    """Time between consecutive kernels of the queue that runs the wide layers (bench.py's split
+    pipeline), and what the other queues did meanwhile."""
+    rows = []
+    with open(trace) as fh:
+        for r in csv.DictReader(fh):
+            rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Queue_Id'], r['Kernel_Name']))
+    rows.sort()
+    perq = defaultdict(list)
+    for r in rows:
+        perq[r[2]].append(r)
+    wq = max(perq, key=lambda q: sum(1 for r in perq[q] if 'conv_f32_dma_kernel<128' in r[3]))
+    w = perq[wq]
+    # steady state: the middle half of the wide queue's kernels
+    w = w[len(w) // 4: 3 * len(w) // 4]
+    others = [r for r in rows if r[2] != wq and w[0][0] <= r[0] <= w[-1][1]]
+    import bisect
+    ostarts = [r[0] for r in others]
+    g, busy = [], 0
+    for a, b in zip(w, w[1:]):
+        gap = b[0] - a[1]
+        busy += a[1] - a[0]
+        lo, hi = bisect.bisect_left(ostarts, a[1]), bisect.bisect_right(ostarts, b[0])
+        g.append((gap, hi - lo, a[3], b[3]))
+    span = w[-1][1] - w[0][0]
+    gs = sorted(x[0] for x in g)
+    print(f'wide queue {wq}: {len(w)} kernels, busy {busy / span:.2f} of the span, gaps: mean {sum(gs) / len(gs) / 1e3:.1f} us, '
+          f'median {gs[len(gs) // 2] / 1e3:.1f}, p90 {gs[int(len(gs) * .9)] / 1e3:.1f}, max {gs[-1] / 1e3:.1f}')
+    by = defaultdict(list)
+    for gap, n, a, b in g:
+        short = lambda n_: n_.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0][:34]  # noqa: E731
+        by[(short(a), short(b))].append((gap, n))
+    for k, v in sorted(by.items(), key=lambda kv: -sum(x[0] for x in kv[1]))[:14]:
+        print(f'  {k[0]:34s} -> {k[1]:34s} n={len(v):4d} mean gap {sum(x[0] for x in v) / len(v) / 1e3:7.1f} us, '
+              f'kernels started on other queues meanwhile {sum(x[1] for x in v) / len(v):.1f}')
+
+
+if __name__ == '__main__' and len(sys.argv) == 2:
+    gaps(sys.argv[1])
