@@ -356,10 +356,14 @@ def main():
         # front + narrow layers of frame i on light[i % 2], the wide layers of every frame on one
         # stream; the three streams on hardware queues of their own (LidarBackbone.capture_split)
         from sparsefusion_amd.streams import concurrent_streams
-        (light0, light1, wide_st), n_queues = concurrent_streams(dev, 3)
+        # bf16 (front-bound): the narrow layers on the fourth queue instead of behind their front
+        # (1125 vs 1096 frames/s; fp32: 494 vs 496 -- profiles/r02_queue_probe*.txt)
+        (light0, light1, wide_st, narrow_st), n_queues = concurrent_streams(dev, 4)
+        if args.dtype != 'bf16':
+            narrow_st = None
         streams = [wide_st for _ in lanes]
     else:
-        n_queues = None
+        n_queues, narrow_st = None, None
         streams = [torch.cuda.Stream(device=dev) for _ in lanes]
     frames = [[torch.from_numpy(host_frames[f * B + b]).to(dev) for b in range(B)]
               for f in range(args.frames)]
@@ -376,7 +380,8 @@ def main():
                     fns = [(lambda f=f, lane=lane: lane.enqueue(f, vf)) for f in frames]
                 elif split:
                     light = (light0, light1)[li % 2]
-                    sfs = [lane.capture_split(f, [light, light, wide_st], voxel_features=vf) for f in frames]
+                    sfs = [lane.capture_split(f, [light, narrow_st or light, wide_st], voxel_features=vf)
+                           for f in frames]
                     split_frames.append(sfs)
                     fns = [(lambda sf=sf: sf.replay(timed=wide_events)) for sf in sfs]
                 else:
@@ -556,8 +561,10 @@ def main():
                        'voxels_frame0': detail['counts'][0] if detail else None,
                        'bev_backbone': 'SECOND + SECONDFPN (fp32) on the BEV map' if args.second else None,
                        'hip_graph': not args.no_graph, 'frames_in_flight': args.streams,
-                       'pipeline': ('split: front + narrow layers on 2 streams by frame parity, wide layers '
-                                    f'on 1, {n_queues} hardware queues' if split else
+                       'pipeline': (('split: front on 2 streams by frame parity, narrow layers on 1, wide layers '
+                                     if narrow_st is not None else
+                                     'split: front + narrow layers on 2 streams by frame parity, wide layers ') +
+                                    f'on 1, {n_queues} hardware queues found' if split else
                                     'one graph per frame, coordinate phase forked inside'), 'sharding': 'frames by rank, no collective'},
             'roofline': roofline,
             'verified': {'batches_checked': verified, 'rechecked_on_another_rank': len(recheck),

@@ -36,6 +36,7 @@ def main():
     ap.add_argument('--frames', type=int, default=4)
     ap.add_argument('--lanes', type=int, default=4)
     ap.add_argument('--pairs', action='store_true')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'])
     ap.add_argument('--layouts', action='store_true')
     ap.add_argument('--hide', action='store_true', help='light segments beside the wide layers: hidden share')
     ap.add_argument('--tail', action='store_true', help='with --layouts: only the variants that move the tail of a frame')
@@ -45,8 +46,8 @@ def main():
     host = [synth.nuscenes_frame(i) for i in range(args.frames)]
     max_pts = max(p.shape[0] for p in host)
     frames = [[torch.from_numpy(p).to(dev)] for p in host]
-    cfg, ecfg, sd, enc, bb = bench.build_backbone('nusc', dev, 1, max_pts)
-    lanes = [bb] + [LidarBackbone(cfg['pts_voxel_layer'], enc, dev, max_pts, batch_size=1)
+    cfg, ecfg, sd, enc, bb = bench.build_backbone('nusc', dev, 1, max_pts, True, args.dtype)
+    lanes = [bb] + [LidarBackbone(cfg['pts_voxel_layer'], enc, dev, max_pts, batch_size=1, dtype=args.dtype)
                     for _ in range(max(args.lanes, 2) - 1)]
     pool = [torch.cuda.Stream(device=dev) for _ in range(args.pool)]
     cls = queue_classes(pool)
@@ -155,6 +156,12 @@ def main():
                 ('same, cut in front of 32->64', 4, parity(4, (Q(3),)), 10),
                 ('same, cut behind the first 64->64', 4, parity(4, (Q(3),)), 12),
                 ('same, 64- and 128-channel layers apart', 4, parity(4, (Q(3), Q(2))), [11, 16]),
+                ('front by frame parity | all layers', 4, tuple((Q(i % 2), Q(3), Q(3)) for i in range(4)), None),
+                ('front by frame parity | narrow | wide', 4, tuple((Q(i % 2), Q(2), Q(3)) for i in range(4)), None),
+                ('front by frame parity | narrow | wide', 6, tuple((Q(i % 2), Q(2), Q(3)) for i in range(6)), None),
+                ('front on 3 streams | all layers', 6, tuple((Q(i % 3), Q(3), Q(3)) for i in range(6)), None),
+                ('front+narrow by parity | wide, cut 6', 4, parity(4, (Q(3),)), 6),
+                ('front+narrow by parity | wide, cut 16', 4, parity(4, (Q(3),)), 16),
             ]
             def par_tail(nl, cutlist):
                 # the tail of every frame on the fourth queue (on a light stream it would queue up
