@@ -112,10 +112,31 @@ def test_split_pipeline_frames_in_flight(dev):
             f.replay()
             torch.cuda.synchronize()
             assert torch.equal(lane.bev, expect[0])
+        # a last cut == number of layers: the dense map as a segment of its own
+        f3 = lanes[2].capture_split(pts[1], [light0, light0, wide, light1], cut=[11, len(lanes[2].layers)])
+        assert len(f3.graphs) == 3
+        f3.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(lanes[2].bev, expect[1])
     with pytest.raises(ValueError):
         lanes[0].capture_split(pts[0], [wide, wide])
     with pytest.raises(ValueError):
         lanes[0].capture_split(pts[0], [wide, wide, wide], cut=[5, 5])
+
+
+def test_concurrent_streams(dev):
+    """streams.queue_classes partitions the candidates (every stream in exactly one class, streams of
+    one class really serialise: checked by the probe itself) and concurrent_streams hands out
+    DISTINCT streams, from different classes while there are enough."""
+    from sparsefusion_amd.streams import concurrent_streams, queue_classes
+    pool = [torch.cuda.Stream(device=dev) for _ in range(6)]
+    classes = queue_classes(pool)
+    assert sorted(i for c in classes for i in c) == list(range(6))
+    assert 1 <= len(classes) <= 6
+    for n in (1, 3, 5):
+        streams, found = concurrent_streams(dev, n)
+        assert len(streams) == n and len({s.cuda_stream for s in streams}) == n
+        assert 1 <= found <= n
 
 
 def test_voxel_cap_inside_pipeline(dev, oracle):
