@@ -160,6 +160,9 @@ def main():
                 ('front by frame parity | narrow | wide', 4, tuple((Q(i % 2), Q(2), Q(3)) for i in range(4)), None),
                 ('front by frame parity | narrow | wide', 6, tuple((Q(i % 2), Q(2), Q(3)) for i in range(6)), None),
                 ('front on 3 streams | all layers', 6, tuple((Q(i % 3), Q(3), Q(3)) for i in range(6)), None),
+                ('front+narrow by parity | wide by parity', 4, tuple((Q(i % 2), Q(i % 2), Q(2 + i % 2)) for i in range(4)), None),
+                ('front+narrow by parity | wide by parity', 6, tuple((Q(i % 2), Q(i % 2), Q(2 + i % 2)) for i in range(6)), None),
+                ('front+narrow by parity | wide by parity', 2, tuple((Q(i % 2), Q(i % 2), Q(2 + i % 2)) for i in range(2)), None),
                 ('front+narrow by parity | wide, cut 6', 4, parity(4, (Q(3),)), 6),
                 ('front+narrow by parity | wide, cut 16', 4, parity(4, (Q(3),)), 16),
             ]
