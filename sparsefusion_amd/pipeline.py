@@ -640,3 +640,92 @@ class LidarBackbone:
             gstreams.append(streams[i])
             i = j
         return _SplitFrame(self, graphs, gstreams)
+
+
+class FramePipeline:
+    """Arbitrary frames through CAPTURED graphs, several in flight (a serving / evaluation loop).
+
+    `LidarBackbone.capture*` binds a graph to its input tensors and to their point count.  This
+    class gives every LidarBackbone object in flight a static point buffer of `max_points` rows: a
+    frame is copied into it, the rows behind it hold a point just outside `point_cloud_range`
+    (the voxelizer rejects it exactly as it rejects any out-of-range point of a real sweep,
+    voxelization_cpu.cpp:32-37,71), and the object's split graphs -- captured once, on its first
+    frame -- are replayed.  Layout as in bench.py: front + narrow layers on one of two streams by
+    frame parity, the wide layers of every frame on one stream, `in_flight` objects.
+
+        pipe = FramePipeline(cfg['pts_voxel_layer'], encoder, 'cuda:0', max_points=400_000, num_features=5)
+        t = pipe.submit(points)            # (n, 5) f32 tensor, host or device; returns a ticket
+        bev = pipe.result(t)               # waits for that frame only; valid until `in_flight` more
+                                           # frames have been submitted (the object is reused)
+    """
+
+    def __init__(self, voxel_layer_cfg, encoder, device, max_points, num_features, in_flight=4,
+                 **backbone_kw):
+        from .streams import concurrent_streams
+        self.dev = torch.device(device)
+        self.max_points, self.F = int(max_points), int(num_features)
+        if in_flight < 1:
+            raise ValueError('in_flight >= 1')
+        if backbone_kw.get('batch_size', 1) != 1:
+            raise NotImplementedError('FramePipeline runs one sample per frame')
+        (self.light0, self.light1, self.wide), self.hardware_queues = concurrent_streams(self.dev, 3)
+        rng = voxel_layer_cfg['point_cloud_range']
+        vs = voxel_layer_cfg['voxel_size']
+        # x beyond the upper bound by ten voxels: floor((x - lo) / vs) >= grid, rejected; finite, exact
+        sentinel = torch.zeros(self.F, dtype=torch.float32)
+        sentinel[0] = float(rng[3]) + 10.0 * float(vs[0])
+        self._sentinel = sentinel.to(self.dev)
+        self.lanes = []
+        for _ in range(in_flight):
+            bb = LidarBackbone(voxel_layer_cfg, encoder, self.dev, self.max_points, batch_size=1,
+                               **backbone_kw)
+            buf = self._sentinel.repeat(self.max_points, 1).contiguous()
+            self.lanes.append(dict(bb=bb, buf=buf, valid=0, frame=None, ticket=-1))
+        self._next = 0
+
+    def submit(self, points):
+        """Enqueue one frame; returns its ticket.  No host synchronisation when `points` is a
+        device tensor (a pageable host tensor makes the copy itself synchronous)."""
+        if points.dim() != 2 or points.shape[1] != self.F or points.dtype != torch.float32:
+            raise RuntimeError(f'points must be (n, {self.F}) float32')
+        n = int(points.shape[0])
+        if n > self.max_points:
+            raise RuntimeError(f'{n} points > max_points {self.max_points}')
+        ticket = self._next
+        self._next += 1
+        lane = self.lanes[ticket % len(self.lanes)]
+        bb, buf = lane['bb'], lane['buf']
+        light = (self.light0, self.light1)[ticket % 2]
+        # the object's previous frame still reads the buffer until its front is done; waiting for
+        # the whole frame is the same event the replay waits for anyway
+        if bb._last_segment_done is not None:
+            light.wait_event(bb._last_segment_done)
+        with torch.cuda.stream(light), torch.no_grad():
+            if n:
+                buf[:n].copy_(points, non_blocking=True)
+            if lane['valid'] > n:
+                buf[n:lane['valid']] = self._sentinel
+            lane['valid'] = n
+        if lane['frame'] is None:      # first frame of this object: capture (host-synchronous)
+            with torch.no_grad():
+                lane['frame'] = bb.capture_split([buf], [light, light, self.wide])
+        lane['frame'].streams[0] = light     # (an odd in_flight alternates an object's front stream)
+        with torch.cuda.stream(self.wide):
+            lane['frame'].replay()
+        lane['ticket'] = ticket
+        return ticket
+
+    def result(self, ticket):
+        """BEV tensor of frame `ticket` (waits for it).  The tensor is the object's static output:
+        read or copy it before `in_flight` further frames have been submitted."""
+        lane = self.lanes[ticket % len(self.lanes)]
+        if lane['ticket'] != ticket:
+            raise RuntimeError(f'frame {ticket} is gone: its object now holds frame {lane["ticket"]}')
+        lane['bb']._last_segment_done.synchronize()
+        bb = lane['bb']
+        return bb.bev_out if bb.bev_backbone is not None else bb.bev
+
+    def results(self, ticket):
+        """`LidarBackbone.results()` of frame `ticket` (counts, coors, voxels ... of the frame)."""
+        self.result(ticket)
+        return self.lanes[ticket % len(self.lanes)]['bb'].results()

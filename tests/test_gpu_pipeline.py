@@ -124,6 +124,45 @@ def test_split_pipeline_frames_in_flight(dev):
         lanes[0].capture_split(pts[0], [wide, wide, wide], cut=[5, 5])
 
 
+@pytest.mark.parametrize('in_flight', [3, 4])
+def test_frame_pipeline_arbitrary_frames(dev, in_flight):
+    """FramePipeline: frames of any size through graphs captured once per object (static point
+    buffer, the rows behind the frame hold an out-of-range point); every frame equals the eager
+    enqueue bit for bit -- map, coordinates, point counts -- also when a small frame follows a
+    large one on the same object, from host and from device tensors."""
+    from sparsefusion_amd.pipeline import FramePipeline
+    enc, sd, cfg = make_encoder(dev, 5, 15)
+    sizes = [5000, 2000, 4200, 3100, 6000, 1500, 3600, 5200, 800]
+    host = [small_points(500 + i, n) for i, n in enumerate(sizes)]
+    ref = LidarBackbone(VL, enc, dev, max_points=8000, batch_size=1)
+    expect = []
+    with torch.no_grad():
+        for p in host:
+            bev = ref([to_dev(p, dev)]).clone()
+            r = ref.results()
+            expect.append((bev, r['coors'].clone(), r['num_points'].clone()))
+    pipe = FramePipeline(VL, enc, dev, max_points=8000, num_features=5, in_flight=in_flight)
+    assert 1 <= pipe.hardware_queues <= 3
+    tickets = []
+    for i, p in enumerate(host):
+        pts = torch.from_numpy(p) if i % 2 else to_dev(p, dev)     # host and device inputs
+        tickets.append(pipe.submit(pts))
+        if i >= in_flight - 1:                    # the oldest frame still held by an object
+            j = i - (in_flight - 1)
+            assert torch.equal(pipe.result(tickets[j]), expect[j][0]), j
+            r = pipe.results(tickets[j])
+            assert r['overflow'] == 0
+            assert torch.equal(r['coors'], expect[j][1]) and torch.equal(r['num_points'], expect[j][2])
+    for j in range(len(host) - in_flight + 1, len(host)):
+        assert torch.equal(pipe.result(tickets[j]), expect[j][0]), j
+    with pytest.raises(RuntimeError):
+        pipe.result(tickets[0])                   # its object holds a later frame by now
+    with pytest.raises(RuntimeError):
+        pipe.submit(torch.zeros((9000, 5)))
+    with pytest.raises(RuntimeError):
+        pipe.submit(torch.zeros((10, 4)))
+
+
 def test_concurrent_streams(dev):
     """streams.queue_classes partitions the candidates (every stream in exactly one class, streams of
     one class really serialise: checked by the probe itself) and concurrent_streams hands out

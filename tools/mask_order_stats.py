@@ -50,7 +50,7 @@ def main():
             nat = np.arange(nrow)
             line = [f'rows {nrow:7d} pairs/row {num.sum() / nrow:5.2f} | natural {waste(masks, nat):.3f}',
                     f'global {waste(masks, np.argsort(masks, kind="stable")):.3f}']
-            for ch in (512, 1024, 2048, 4096, 8192, 16384):
+            for ch in (256, 512, 1024, 2048, 4096, 8192, 16384):
                 order = np.concatenate([s + np.argsort(masks[s:s + ch], kind='stable')
                                         for s in range(0, nrow, ch)])
                 line.append(f'c{ch} {waste(masks, order):.3f}')
