@@ -306,6 +306,10 @@ def main():
     ap.add_argument('--strided-growth', type=float, default=None,
                     help='bound on output/input rows of a strided conv for sizing (default: the '
                          'geometric worst case, 8); overflow is detected, never silent')
+    ap.add_argument('--frame-pipeline', action='store_true',
+                    help='submit the frames through pipeline.FramePipeline (graphs captured once per '
+                         'object, every frame COPIED into a static point buffer first: what a caller '
+                         'with a stream of new frames runs) instead of graphs bound to the resident frames')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-overlap', action='store_true',
                     help='coordinate phase on the main stream instead of a forked one')
@@ -393,6 +397,19 @@ def main():
             st, fns = steps[i % len(steps)]
             with torch.cuda.stream(st):
                 fns[(i // len(steps)) % len(fns)]()
+
+        if args.frame_pipeline:
+            if B != 1 or not split or args.second or args.workload != 'nusc':
+                raise SystemExit('--frame-pipeline: nuScenes workload, one frame per step, split pipeline')
+            from sparsefusion_amd.pipeline import FramePipeline
+            pipe = FramePipeline(cfg['pts_voxel_layer'], enc, dev, max_pts, frames[0][0].shape[1],
+                                 in_flight=args.streams, dtype=args.dtype,
+                                 strided_growth=args.strided_growth)
+
+            def run(i):   # noqa: F811
+                pipe.submit(frames[i % len(frames)][0])
+            for i in range(2 * args.streams):     # every object captures on its first frame
+                run(i)
 
         for i in range(args.warmup):
             run(i)
@@ -561,6 +578,7 @@ def main():
                        'voxels_frame0': detail['counts'][0] if detail else None,
                        'bev_backbone': 'SECOND + SECONDFPN (fp32) on the BEV map' if args.second else None,
                        'hip_graph': not args.no_graph, 'frames_in_flight': args.streams,
+                       'frame_pipeline': bool(args.frame_pipeline),
                        'pipeline': (('split: front on 2 streams by frame parity, narrow layers on 1, wide layers '
                                      if narrow_st is not None else
                                      'split: front + narrow layers on 2 streams by frame parity, wide layers ') +
