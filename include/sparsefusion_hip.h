@@ -336,7 +336,8 @@ SF_API int sf_sparse_conv_f32_ordered(const float *features_in, int n_in_bound, 
 
 /* Replaces SparseConvTensor.dense() + view (mmdet3d/ops/spconv/structure.py:55-64,
  * mmdet3d/models/middle_encoders/sparse_encoder.py:122-125): out (B, C*D, H, W) f32 with
- * channel = c*D + z, zero where inactive (the zero fill is part of this call). */
+ * channel = c*D + z, zero where inactive (the zero fill is part of this call, done by kernels:
+ * like every entry point of this library it captures into a HIP graph as kernel nodes only). */
 SF_API int sf_dense_bev(const float *features, const int *indices, const int *n_dev, int n_bound,
                         int channels, int batch, int D, int H, int W, float *out, void *stream);
 
