@@ -670,14 +670,21 @@ conv_f32_dma_kernel(const float *__restrict__ feat, unsigned feat_bytes, PlanVie
 
   for (int run0 = 0; run0 < my_n; run0 += kRun) {
     const int cnt = (my_n - run0 < kRun) ? my_n - run0 : kRun;
-    __syncthreads();   // the previous run is drained (fence: every DMA has landed)
+    // the previous run is drained: its last (padding) phases still have zero-fill DMAs in flight,
+    // and nothing the compiler knows of makes the barrier below wait for them
+    __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0)
+    __syncthreads();
     if (tid < cnt) {
       const int i = run0 + tid;
       s_tiles[tid] = pv.sched[(size_t)i * G + ((i & 1) ? G - 1 - b : b)];
     }
+    // (every barrier of this kernel follows an explicit vector-memory wait: the set-up barriers a
+    // full drain, the phase barriers the counted one -- tests/test_isa_dma_wait.py holds the ISA to it)
+    __builtin_amdgcn_s_waitcnt(0x0070);
     __syncthreads();
     if (tid < 2 * kHdrInts && (tid >> 5) < cnt)
       s_hdr[tid] = pv.hdr[(size_t)s_tiles[tid >> 5] * kHdrInts + (tid & 31)];
+    __builtin_amdgcn_s_waitcnt(0x0070);
     __syncthreads();
 
     int gj = 0, ga = 0;
@@ -725,12 +732,15 @@ conv_f32_dma_kernel(const float *__restrict__ feat, unsigned feat_bytes, PlanVie
         const int *ip = pv.nbrs + (size_t)(iD & 31) * pv.s_stride + (size_t)tD * TM;
 #pragma unroll
         for (int j = 0; j < IPW; ++j) inew[j] = ip[prow[j]];
-        const bool live = (iC >> 9) & 1;
+        // a padding phase fetches row -1: out of range, zeros land in LDS, no fetch.  (An OR with a
+        // scalar mask, not a select: the select became a branch around the first DMA.)
+        const unsigned dead = ((iC >> 9) & 1) ? 0u : 0xFFFFFFFFu;
 #pragma unroll
-        for (int j = 0; j < IPW; ++j) {
-          const int src = live ? ireg[j] : -1;   // -1: out of range, zeros land in LDS, no fetch
-          lds_dma16(rs, nxt2 + (wave * IPW + j) * 1024, (unsigned)src * ROWB + soff[j]);
-        }
+        for (int j = 0; j < IPW; ++j)
+          lds_dma16(rs, nxt2 + (wave * IPW + j) * 1024, ((unsigned)ireg[j] | dead) * ROWB + soff[j]);
+        // compiler fence (no instruction): the memory operations below stay below the DMA, the
+        // order kWaitN counts on (tests/test_isa_dma_wait.py checks the emitted ISA)
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int j = 0; j < IPW; ++j) ireg[j] = inew[j];
       }
@@ -832,8 +842,12 @@ conv_f32_dma_kernel(const float *__restrict__ feat, unsigned feat_bytes, PlanVie
       if ((fl & 8) && tid < kHdrInts && cj + 2 < cnt) s_hdr[((cj + 2) % 3) * kHdrInts + tid] = hreg;
       // end of the phase: this wave's share of the rows of phase q+1 has landed (vmcnt counts in
       // order), LDS writes are done, then the barrier -- no fence, the younger DMA stays in flight
+      // (compiler fences around the pair: no memory access -- the LDS reads of the next phase
+      // included -- moves across the counted wait and the raw barrier)
+      asm volatile("" ::: "memory");
       __builtin_amdgcn_s_waitcnt((kWaitN & 15) | ((kWaitN >> 4) << 14) | (7 << 4) | (0 << 8));
       __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
     };
     do {
       phase(std::integral_constant<int, 0>{});

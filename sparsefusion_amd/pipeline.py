@@ -700,6 +700,12 @@ class FramePipeline:
         # the whole frame is the same event the replay waits for anyway
         if bb._last_segment_done is not None:
             light.wait_event(bb._last_segment_done)
+        if points.is_cuda:
+            # `points` may still be being written by work the caller queued on ITS stream, and the
+            # caching allocator may hand its memory out again once the caller drops it: order the
+            # copy behind the producer and tell the allocator that `light` reads the tensor
+            light.wait_stream(torch.cuda.current_stream(self.dev))
+            points.record_stream(light)
         with torch.cuda.stream(light), torch.no_grad():
             if n:
                 buf[:n].copy_(points, non_blocking=True)

@@ -163,6 +163,32 @@ def test_frame_pipeline_arbitrary_frames(dev, in_flight):
         pipe.submit(torch.zeros((10, 4)))
 
 
+def test_frame_pipeline_orders_behind_the_producer(dev):
+    """A device tensor handed to submit() may still be being written by work queued on the caller's
+    stream (here: a long spin kernel, then the copy that fills it) and may be freed right after
+    the call: the pipeline's copy has to wait for the producer and pin the memory."""
+    from sparsefusion_amd.pipeline import FramePipeline
+    enc, sd, cfg = make_encoder(dev, 5, 15)
+    host = small_points(611, 4000)
+    ref = LidarBackbone(VL, enc, dev, max_points=8000, batch_size=1)
+    with torch.no_grad():
+        expect = ref([to_dev(host, dev)]).clone()
+    pipe = FramePipeline(VL, enc, dev, max_points=8000, num_features=5, in_flight=2)
+    pipe.result(pipe.submit(to_dev(small_points(612, 3000), dev)))   # captures lane 0
+    pipe.result(pipe.submit(to_dev(small_points(613, 3000), dev)))   # captures lane 1
+    src = to_dev(host, dev)
+    torch.cuda.synchronize()
+    for _ in range(2):                                # both lanes
+        pts = torch.full_like(src, 1e6)               # stale content = out-of-range points
+        torch.cuda._sleep(40_000_000)                 # ~20 ms: the producer below is far from done
+        pts.copy_(src)                                #   ... when submit() returns
+        t = pipe.submit(pts)
+        del pts                                       # the allocator may recycle it at once
+        junk = torch.full_like(src, -1e6)             # (and usually hands out the same block)
+        assert torch.equal(pipe.result(t), expect)
+        del junk
+
+
 def test_concurrent_streams(dev):
     """streams.queue_classes partitions the candidates (every stream in exactly one class, streams of
     one class really serialise: checked by the probe itself) and concurrent_streams hands out

@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Where does a frame of bench.py's split pipeline wait?  Rebuilds the same pipeline (4 objects in
+flight, front + narrow layers on one of two streams by frame parity, wide layers of every frame on
+one stream) and records, per frame, the HOST time of every call of `_SplitFrame.replay` and the
+GPU time of the segment boundaries (timing events against one base event).
+
+    python tools/pipeline_probe.py [--frames 40] [--lanes 4]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from sparsefusion_amd import synth  # noqa: E402
+from sparsefusion_amd.pipeline import LidarBackbone  # noqa: E402
+from sparsefusion_amd.streams import concurrent_streams  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--frames', type=int, default=40)
+    ap.add_argument('--lanes', type=int, default=4)
+    ap.add_argument('--distinct', type=int, default=4)
+    args = ap.parse_args()
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(dev)
+    host = [synth.nuscenes_frame(i) for i in range(args.distinct)]
+    max_pts = max(p.shape[0] for p in host)
+    cfg, ecfg, sd, enc, bb = bench.build_backbone('nusc', dev, 1, max_pts)
+    lanes = [bb] + [LidarBackbone(cfg['pts_voxel_layer'], enc, dev, max_pts) for _ in range(args.lanes - 1)]
+    (l0, l1, wide), nq = concurrent_streams(dev, 3)
+    print('hardware queues found', nq)
+    frames = [[torch.from_numpy(p).to(dev)] for p in host]
+    sfs = []
+    with torch.no_grad():
+        for li, lane in enumerate(lanes):
+            light = (l0, l1)[li % 2]
+            sfs.append([lane.capture_split(f, [light, light, wide]) for f in frames])
+    torch.cuda.synchronize()
+
+    base = torch.cuda.Event(enable_timing=True)
+    recs = []
+
+    def replay(sf, rec):
+        """_SplitFrame.replay with host stamps and timing events."""
+        o = sf.owner
+        prev = o._last_segment_done
+        for i, (g, st, ev) in enumerate(zip(sf.graphs, sf.streams, sf.events)):
+            h0 = time.perf_counter()
+            if prev is not None:
+                st.wait_event(prev)
+            h1 = time.perf_counter()
+            with torch.cuda.stream(st):
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(st)
+                h2 = time.perf_counter()
+                g.replay()
+                h3 = time.perf_counter()
+                e1.record(st)
+                ev.record(st)
+            h4 = time.perf_counter()
+            rec.append((i, h0, h1, h2, h3, h4, e0, e1))
+            prev = ev
+        o._last_segment_done = prev
+
+    for rnd in range(2):       # round 0 warms up
+        recs.clear()
+        torch.cuda.synchronize()
+        base.record()
+        t0 = time.perf_counter()
+        for i in range(args.frames):
+            rec = []
+            replay(sfs[i % len(lanes)][(i // len(lanes)) % len(frames)], rec)
+            recs.append(rec)
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        print(f'round {rnd}: host submit {1e3 * (t1 - t0):.2f} ms, all done {1e3 * (t2 - t0):.2f} ms '
+              f'= {1e3 * (t2 - t0) / args.frames:.3f} ms/frame')
+    print('frame: host submit [ms from t0] (wait_event, replay calls) | light seg GPU start..end | wide seg GPU start..end')
+    for i, rec in enumerate(recs):
+        parts = []
+        for (si, h0, h1, h2, h3, h4, e0, e1) in rec:
+            parts.append(f'seg{si} host {1e3 * (h0 - t0):7.2f} +wait {1e3 * (h1 - h0):5.2f} +replay {1e3 * (h3 - h2):5.2f} '
+                         f'| gpu {base.elapsed_time(e0):7.2f}..{base.elapsed_time(e1):7.2f}')
+        print(f'{i:3d} ' + '  ||  '.join(parts))
+
+
+if __name__ == '__main__':
+    main()
