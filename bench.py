@@ -288,7 +288,10 @@ def main():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--workload', default='nusc', choices=['nusc', 'waymo'])
-    ap.add_argument('--frames', type=int, default=4, help='distinct synthetic frames per rank')
+    ap.add_argument('--frames', type=int, default=None,
+                    help='distinct synthetic frames (batches) per rank; default 4 on one GPU, and '
+                         '64 / (N * batch) on N > 1 GPUs: the 64-frame stream of BASELINE configs[3] '
+                         'dealt round-robin over the ranks')
     ap.add_argument('--batch', type=int, default=1, help='frames per step (samples per batch)')
     ap.add_argument('--streams', type=int, default=None,
                     help='frames in flight per GPU, each with its own workspace (default 4 with the '
@@ -338,6 +341,8 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    if args.frames is None:
+        args.frames = 4 if world == 1 else max(1, 64 // (world * args.batch))
     split = not (args.single_graph or args.no_graph)
     if args.streams is None:
         args.streams = 4 if split else 2
@@ -520,6 +525,10 @@ def main():
             roofline['traffic'], roofline['traffic_source'] = measured_traffic(heavy['kernel'], dom[2])
             roofline['launches_per_frame'] = gd['launches']
             roofline['avg_launch_us'] = round(avg_s * 1e6, 2)
+            # avg_launch_us (and so `achieved`) is measured with the GPU to itself, after the timed
+            # region; `value` is measured in the running pipeline, where the same launches share the
+            # CUs with the other streams' kernels and take longer (profiles/: rocprofv3 of this command)
+            roofline['timing'] = 'alone'
             if wide_ms is not None:
                 # for the record: start-to-end of the wide-layer graph in the timed region and alone.
                 # The difference is time between its kernels (the queue waits while kernels of the

@@ -96,7 +96,10 @@ SF_API int sf_hard_voxelize(const float *points, int n, int f, const float voxel
  *  points at max_points 10, i.e. a nuScenes-shaped 10-sweep frame), else SF_ERR_WORKSPACE.
  *  All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two
  *  host threads) race; serialise them.  Consecutive calls are independent (the scratch is
- *  re-initialised by each call). */
+ *  re-initialised by each call).
+ *  The FIRST call on a device resolves the array's device address (hipGetSymbolAddress, under a
+ *  mutex; not an allocation) and keeps it: make that call eagerly, outside a capture; every later
+ *  call on the device may be captured (tests/test_zz_no_alloc.py replays one). */
 SF_API int sf_hard_voxelize_static(const float *points, int n, int f, const float voxel_size[3],
                                    const float coors_range[6], int max_points, int max_voxels,
                                    float *voxels, int *coors, int coors_stride, int batch_idx,
@@ -237,9 +240,11 @@ SF_API int sf_pack_filters_f32(const float *w_kio, int K, int cin, int cout, flo
  *     y = conv(x) * scale + shift (+ residual) ; ReLU
  * i.e. eval-mode BatchNorm1d folded (make_sparse_convmodule, mmdet3d/ops/sparse_block.py:
  * 142-204) and the SparseBasicBlock tail (sparse_block.py:127-137).  scale/shift/residual may
- * be NULL (plain convolution).  features_in is (n_in, cin_padded) f32; out (n_out, cout).
+ * be NULL (plain convolution).  features_in is (n_in_bound, cin_padded) f32 -- n_in_bound rows
+ * must be addressable: the gathers are bounds checked against it, and the table must stay below
+ * 2 GiB --; out (n_out, cout).
  * k_first >= 0 accumulates that offset first (the reference adds the SubM centre first). */
-SF_API int sf_sparse_conv_f32(const float *features_in, int cin_padded, const int *nbr,
+SF_API int sf_sparse_conv_f32(const float *features_in, int n_in_bound, int cin_padded, const int *nbr,
                               int nbr_stride, int K, int k_first, const float *w_packed, int cout,
                               const float *scale, const float *shift, const float *residual,
                               int relu, float *out, const int *n_out_dev, int n_out_bound,
@@ -283,7 +288,8 @@ SF_API const char *sf_last_conv_kernel(void);
 
 /* Diagnostic hooks exported by the library but NOT part of this interface (no declaration here
  * on purpose): sf_debug_conv_profile, sf_debug_ordered_profile (a device buffer every convolution
- * launch adds in-kernel cycle stamps to) and sf_debug_conv_row_order.  They set process-wide
+ * launch adds in-kernel cycle stamps to), sf_debug_conv_row_order and sf_debug_ordered_grid_cap (a
+ * test hook that limits the persistent grid of the ordered kernels).  They set process-wide
  * pointers read by every later launch on every stream: not thread- or stream-safe, used by
  * tools/prof_conv.py / tools/prof_ordered.py / tools/ab_ordered.py only; NULL (the initial state)
  * turns them off. */

@@ -49,7 +49,7 @@ SIGNATURES = {
     'sf_indice_pairs_to_table': (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     'sf_conv_padded_cin': (_i, [_i]),
     'sf_pack_filters_f32': (_i, [_vp, _i, _i, _i, _vp, _vp]),
-    'sf_sparse_conv_f32': (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp,
+    'sf_sparse_conv_f32': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp,
                                 _i, _vp]),
     'sf_last_conv_kernel': (C.c_char_p, []),
     'sf_row_order_workspace': (_sz, [_i]),

@@ -331,11 +331,16 @@ int launch(const float *in, const float *wp, const float *scale, const float *sh
            Conv2dArgs a, hipStream_t st) {
   using G = Geo<KS, S, TH, NG>;
   auto kern = conv2d_f32_kernel<KS, S, TH, NG>;
-  static bool attr_set = false;  // per instantiation; the attribute is sticky per function
-  if (G::LDS_BYTES > 48 * 1024 && !attr_set) {
-    SF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
-    attr_set = true;
+  static bool attr_set[kSfMaxDevices] = {};  // per instantiation and device: the attribute is sticky
+  if (G::LDS_BYTES > 48 * 1024) {
+    int dev = 0;
+    SF_CHECK_HIP(hipGetDevice(&dev));
+    SF_CHECK_ARG(dev >= 0 && dev < kSfMaxDevices, "device ordinal %d out of range", dev);
+    if (!attr_set[dev]) {
+      SF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
+      attr_set[dev] = true;
+    }
   }
   a.nyt = sf_div_up(a.Ho, TH);
   a.nct = sf_div_up(a.cout_packed, 16 * NG);

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/sparsefusion_hip.h"
 
@@ -41,7 +42,9 @@ static inline int sf_div_up(long long a, long long b) { return (int)((a + b - 1)
 static inline int sf_grid(long long items, int threads) {
   long long b = (items + threads - 1) / threads;
   if (b < 1) b = 1;
-  if (b > 2048) b = 2048;
+  static int cap = 0;
+  if (cap == 0) { const char *e = getenv("SF_GRID_CAP"); cap = e ? atoi(e) : 2048; if (cap < 1) cap = 2048; }
+  if (b > cap) b = cap;
   return (int)b;
 }
 
@@ -62,6 +65,37 @@ static __global__ void sf_fill_u32_kernel(uint32_t *__restrict__ p, size_t n, ui
       SF_CHECK_LAUNCH();                                                                          \
     }                                                                                             \
   } while (0)
+
+// Workgroups of `kern` that are resident at once on the CURRENT device (CUs x occupancy), the grid
+// of the persistent kernels.  Looked up once per device ordinal: a process may drive several GPUs,
+// and both the occupancy and the opt-in to more than 48 KB of dynamic LDS belong to a device.
+constexpr int kSfMaxDevices = 64;
+struct SfSlotCache {
+  int slots[kSfMaxDevices];
+};
+template <typename Kern>
+static inline int sf_resident_slots(SfSlotCache &cache, Kern kern, int threads, size_t dyn_lds,
+                                    size_t lds_per_group = 0) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kSfMaxDevices) return -1;
+  if (cache.slots[dev] > 0) return cache.slots[dev];
+  if (dyn_lds > 48 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds) != hipSuccess)
+    return -1;
+  int cus = 256, per_cu = 1;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+    cus = 256;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, dyn_lds) != hipSuccess ||
+      per_cu < 1)
+    per_cu = 1;
+  if (lds_per_group > 0) {   // static LDS the occupancy query may not see
+    int by_lds = (int)((160 * 1024) / lds_per_group);
+    if (per_cu > by_lds) per_cu = by_lds < 1 ? 1 : by_lds;
+  }
+  cache.slots[dev] = cus * per_cu;
+  return cache.slots[dev];
+}
 
 // ---------------------------------------------------------------- device side
 __device__ __forceinline__ uint32_t sf_hash32(uint32_t k) {

@@ -446,19 +446,11 @@ int launch_tile(const ConvArgs &a) {
   } else {
     // grid = workgroups resident at once (CUs x occupancy), a multiple of 8, never more than
     // the bound needs
-    static int slots = 0;
-    if (slots == 0) {
-      int dev = 0, cus = 256, per_cu = 1;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-        cus = prop.multiProcessorCount;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
-              &per_cu, conv_bf16_tile_kernel<CIN, COUT, TM, CG, 4, 2>, 256, 0) != hipSuccess ||
-          per_cu < 1)
-        per_cu = 1;
-      slots = (cus * per_cu) & ~7;
-      if (slots < 8) slots = 8;
-    }
+    static SfSlotCache cache = {};
+    int slots = sf_resident_slots(cache, conv_bf16_tile_kernel<CIN, COUT, TM, CG, 4, 2>, 256, 0);
+    SF_CHECK_ARG(slots > 0, "cannot query the device for the resident workgroups");
+    slots &= ~7;
+    if (slots < 8) slots = 8;
     static int balance = -1;
     if (balance < 0) balance = getenv("SF_BF16_BALANCE") ? atoi(getenv("SF_BF16_BALANCE")) & 1 : 0;
     int grid = (sf_div_up(a.n_out_bound, balance ? 16 : TM) + 7) & ~7;

@@ -932,21 +932,10 @@ int launch(const ConvArgs &a, int balance_default) {
                          64;
   static_assert(lds <= 160 * 1024, "tile does not fit LDS");
   // grid = what is resident at once (CUs x workgroups per CU), never more than the tiles
-  static int slots = 0;
-  if (slots == 0) {
-    int dev = 0, cus = 256, per_cu = 1;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      cus = prop.multiProcessorCount;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &per_cu, sparse_conv_f32_kernel<CIN, COUT, TM, AM, WAVES, ABUF>, WAVES * 64, 0) !=
-            hipSuccess ||
-        per_cu < 1)
-      per_cu = 1;
-    int by_lds = (int)((160 * 1024) / lds);
-    if (per_cu > by_lds) per_cu = by_lds < 1 ? 1 : by_lds;
-    slots = cus * per_cu;
-  }
+  static SfSlotCache cache = {};
+  const int slots = sf_resident_slots(cache, sparse_conv_f32_kernel<CIN, COUT, TM, AM, WAVES, ABUF>,
+                                      WAVES * 64, 0, lds);
+  SF_CHECK_ARG(slots > 0, "cannot query the device for the resident workgroups");
   const int balance = env_balance(balance_default);
   int tiles = sf_div_up(a.n_out_bound, balance ? 32 : TM);
   int cap = balance ? slots : 4096;
@@ -970,21 +959,10 @@ int launch_wide(const ConvArgs &a, int balance_default) {
     constexpr size_t lds = (size_t)(TM + 1) * S::OST * 4 + (size_t)2 * AM * CIN * 4 +
                            (size_t)kMaxK * S::TMP * 5 + (size_t)kMaxK * 4 + (S::NMETA + 1) * 4 + 64;
     static_assert(lds <= 160 * 1024, "tile does not fit LDS");
-    static int slots = 0;
-    if (slots == 0) {
-      int dev = 0, cus = 256, per_cu = 1;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-        cus = prop.multiProcessorCount;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
-              &per_cu, sparse_conv_f32_wide_kernel<CIN, COUT, TM, AM, WAVES, MINW>, WAVES * 64, 0) !=
-              hipSuccess ||
-          per_cu < 1)
-        per_cu = 1;
-      int by_lds = (int)((160 * 1024) / lds);
-      if (per_cu > by_lds) per_cu = by_lds < 1 ? 1 : by_lds;
-      slots = cus * per_cu;
-    }
+    static SfSlotCache cache = {};
+    const int slots = sf_resident_slots(cache, sparse_conv_f32_wide_kernel<CIN, COUT, TM, AM, WAVES, MINW>,
+                                        WAVES * 64, 0, lds);
+    SF_CHECK_ARG(slots > 0, "cannot query the device for the resident workgroups");
     const int balance = env_balance(balance_default);
     int tiles = sf_div_up(a.n_out_bound, balance ? 32 : TM);
     int cap = balance ? slots : 4096;
@@ -1184,7 +1162,7 @@ extern "C" int sf_pad_channels_f32(const float *src, int c_src, float *dst, int 
   return SF_OK;
 }
 
-extern "C" int sf_sparse_conv_f32(const float *features_in, int cin_padded, const int *nbr,
+extern "C" int sf_sparse_conv_f32(const float *features_in, int n_in_bound, int cin_padded, const int *nbr,
                                   int nbr_stride, int K, int k_first, const float *w_packed,
                                   int cout, const float *scale, const float *shift,
                                   const float *residual, int relu, float *out,
@@ -1200,8 +1178,12 @@ extern "C" int sf_sparse_conv_f32(const float *features_in, int cin_padded, cons
                    ((uintptr_t)w_packed & 15) == 0 && ((uintptr_t)residual & 15) == 0 &&
                    ((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0,
                "feature / filter / epilogue pointers must be 16-byte aligned");
-  ConvArgs a{features_in, nbr, nbr_stride, K, k_first, w_packed, scale, shift, residual, relu, out,
-             n_out_dev, n_out_bound, st};
+  const long long feat_bytes = (long long)n_in_bound * cin_padded * 4;
+  SF_CHECK_ARG(n_in_bound >= 1 && feat_bytes < (1ll << 31),
+               "the input feature table (%d rows x %d channels) must hold a row and stay below 2 GiB",
+               n_in_bound, cin_padded);
+  ConvArgs a{features_in, (unsigned)feat_bytes, nbr, nbr_stride, K, k_first, w_packed, scale, shift,
+             residual, relu, out, n_out_dev, n_out_bound, st};
   if (!env_legacy_narrow()) {  // the narrow 3x3x3 layers have a kernel of their own
     const int rc = sf_narrow_conv_f32(cin_padded, cout, a);
     if (rc <= 0) return rc;

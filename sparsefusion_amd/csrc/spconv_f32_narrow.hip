@@ -45,7 +45,7 @@ __device__ __host__ constexpr int visit(int kk) {
 
 template <int CIN, int COUT, bool SUBM, int D, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64)
-narrow_conv_f32_kernel(const float *__restrict__ feat, const int *__restrict__ nbr, int nbr_stride,
+narrow_conv_f32_kernel(const float *__restrict__ feat, unsigned feat_bytes, const int *__restrict__ nbr, int nbr_stride,
                        const float *__restrict__ wpk, const float *__restrict__ scale,
                        const float *__restrict__ shift, const float *__restrict__ residual, int relu,
                        float *__restrict__ out, const int *n_out_dev, int n_out_bound) {
@@ -73,9 +73,10 @@ narrow_conv_f32_kernel(const float *__restrict__ feat, const int *__restrict__ n
   const int lo = xcd * tpx;
   const int hi = (lo + tpx < tiles) ? lo + tpx : tiles;
 
-  // feature table as a raw buffer: valid rows are always in range, kOob is not
+  // feature table as a raw buffer of its real size (< 2 GiB, checked by the entry point): valid
+  // rows are in range, kOob is not
   const __amdgpu_buffer_rsrc_t rsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(feat), 0, 0x7FFFFFFF, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(feat), 0, feat_bytes, 0x00020000);
 
   for (int tile = lo + slot * WAVES + wave; tile < hi; tile += nslots * WAVES) {
     const int row = tile * 16 + ln;
@@ -151,26 +152,16 @@ int launch_narrow(const SfConvArgs &a) {
   constexpr size_t lds = (size_t)kK * (COUT / 16) * (CINP / 16) * 64 * 16;
   static_assert(lds <= 160 * 1024, "filter bank does not fit LDS");
   auto kern = narrow_conv_f32_kernel<CIN, COUT, SUBM, D, WAVES>;
-  static int slots = 0;          // resident workgroups on the device, a multiple of 8
-  if (slots == 0) {
-    if (lds > 48 * 1024)
-      SF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int dev = 0, cus = 256, per_cu = 1;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      cus = prop.multiProcessorCount;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, WAVES * 64, lds) != hipSuccess ||
-        per_cu < 1)
-      per_cu = 1;
-    slots = (cus * per_cu) & ~7;
-    if (slots < 8) slots = 8;
-  }
+  static SfSlotCache cache = {};  // resident workgroups per device
+  int slots = sf_resident_slots(cache, kern, WAVES * 64, lds);
+  SF_CHECK_ARG(slots > 0, "cannot query the device for the resident workgroups");
+  slots &= ~7;                    // a multiple of 8: workgroups are dealt to the XCDs
+  if (slots < 8) slots = 8;
   const int tiles = sf_div_up(a.n_out_bound, 16);
   int grid = (sf_div_up(tiles, WAVES) + 7) & ~7;     // one tile per wave is the least useful grid
   if (grid > slots) grid = slots;
   sf_note_kernel("narrow_conv_f32_kernel<%d, %d, %s, %d, %d>", CIN, COUT, SUBM ? "true" : "false", D, WAVES);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, a.st, a.feat, a.nbr, a.nbr_stride, a.wpk,
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, a.st, a.feat, a.feat_bytes, a.nbr, a.nbr_stride, a.wpk,
                      a.scale, a.shift, a.residual, a.relu, a.out, a.n_out_dev, a.n_out_bound);
   SF_CHECK_LAUNCH();
   return SF_OK;

@@ -858,6 +858,7 @@ conv_f32_dma_kernel(const float *__restrict__ feat, unsigned feat_bytes, PlanVie
 }
 
 unsigned long long *g_ord_prof = nullptr;   // diagnostic only, see sf_debug_ordered_profile
+int g_ord_grid_cap = 0;                     // test hook, see sf_debug_ordered_grid_cap (0 = off)
 
 struct OrdArgs {
   const float *feat;
@@ -888,22 +889,12 @@ int launch_ordered(const OrdArgs &a) {
   constexpr size_t lds = (size_t)2 * kTileRows * (CIN / 4) * 16 + (size_t)(3 * kHdrInts + 128) * 4;
   static_assert(lds <= 160 * 1024, "tile does not fit LDS");
   auto kern = conv_f32_ordered_kernel<CIN, COUT, CG, WAVES, MINB, BFD>;
-  static int slots = 0;          // resident workgroups on the device
-  if (slots == 0) {
-    if (lds > 48 * 1024)
-      SF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int dev = 0, cus = 256, per_cu = 1;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      cus = prop.multiProcessorCount;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, WAVES * 64, lds) != hipSuccess ||
-        per_cu < 1)
-      per_cu = 1;
-    slots = cus * per_cu;
-  }
+  static SfSlotCache cache = {};  // resident workgroups per device
+  const int slots = sf_resident_slots(cache, kern, WAVES * 64, lds);
+  SF_CHECK_ARG(slots > 0, "cannot query the device for the resident workgroups");
   const int tiles = plan_tiles(a.n_out_bound);
-  const int grid = tiles < slots ? tiles : slots;
+  int grid = tiles < slots ? tiles : slots;
+  if (g_ord_grid_cap > 0 && grid > g_ord_grid_cap) grid = g_ord_grid_cap;
   sf_note_kernel("conv_f32_ordered_kernel<%d, %d, %d, %d, %d, %d>", CIN, COUT, CG, WAVES, MINB, BFD);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, a.st, a.feat, a.feat_bytes,
                      plan_view(a.plan, a.n_out_bound), a.K, a.k_first,
@@ -925,19 +916,12 @@ bool env_dma() {
 template <int CIN, int COUT, int CG, int WAVES, int MINB>
 int launch_dma(const OrdArgs &a) {
   auto kern = conv_f32_dma_kernel<CIN, COUT, CG, WAVES, MINB>;
-  static int slots = 0;          // resident workgroups on the device
-  if (slots == 0) {
-    int dev = 0, cus = 256, per_cu = 1;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      cus = prop.multiProcessorCount;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, WAVES * 64, 0) != hipSuccess ||
-        per_cu < 1)
-      per_cu = 1;
-    slots = cus * per_cu;
-  }
+  static SfSlotCache cache = {};  // resident workgroups per device
+  const int slots = sf_resident_slots(cache, kern, WAVES * 64, 0);
+  SF_CHECK_ARG(slots > 0, "cannot query the device for the resident workgroups");
   const int tiles = plan_tiles(a.n_out_bound);
-  const int grid = tiles < slots ? tiles : slots;
+  int grid = tiles < slots ? tiles : slots;
+  if (g_ord_grid_cap > 0 && grid > g_ord_grid_cap) grid = g_ord_grid_cap;
   sf_note_kernel("conv_f32_dma_kernel<%d, %d, %d, %d, %d>", CIN, COUT, CG, WAVES, MINB);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), 0, a.st, a.feat, a.feat_bytes,
                      plan_view(a.plan, a.n_out_bound), a.K, a.k_first,
@@ -1075,9 +1059,17 @@ extern "C" int sf_sparse_conv_f32_ordered(const float *features_in, int n_in_bou
   return SF_ERR_BAD_ARG;
 }
 
-// Diagnostic hook (not part of the documented ABI): a device buffer of 8 uint64 that every ordered
-// conv launch accumulates per-wave cycle stamps into (issue, multiply, epilogue, barrier, phases,
-// multiplying phases, cycles in kernel, waves); NULL = off.
-extern "C" __attribute__((visibility("default"))) void sf_debug_ordered_profile(void *dev_buf8) {
-  g_ord_prof = (unsigned long long *)dev_buf8;
+// Diagnostic hook (not part of the documented ABI): a device buffer of AT LEAST 16 uint64 (nine are
+// written today) that every register-staged ordered conv launch accumulates per-wave stamps into:
+// [0] issue, [1] multiply, [2] epilogue, [3] barrier cycles, [4] phases, [5] multiplying phases,
+// [6] cycles in kernel, [7] waves, [8] 100 MHz ticks in kernel; NULL = off.
+extern "C" __attribute__((visibility("default"))) void sf_debug_ordered_profile(void *dev_buf16) {
+  g_ord_prof = (unsigned long long *)dev_buf16;
+}
+
+// Test hook (not part of the documented ABI): limits the grid of the ordered / DMA kernels to `cap`
+// persistent workgroups (0 = off), so that a small problem gives a workgroup more than kRun tiles
+// (tests/test_gpu_conv_ordered.py::test_many_tiles_per_workgroup).  Process-wide, not thread-safe.
+extern "C" __attribute__((visibility("default"))) void sf_debug_ordered_grid_cap(int cap) {
+  g_ord_grid_cap = cap > 0 ? cap : 0;
 }

@@ -4,6 +4,7 @@
 
 struct SfConvArgs {
   const float *feat;
+  unsigned feat_bytes;   // size of the input feature table: the raw-buffer gathers are bounded by it
   const int *nbr;
   int nbr_stride, K, k_first;
   const float *wpk, *scale, *shift, *residual;

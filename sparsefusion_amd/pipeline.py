@@ -486,7 +486,7 @@ class LidarBackbone:
                     out.data_ptr(), c0 + 4 * rb['dst'], self.sets[rb['dst']]['bound'], st))
             else:
                 chk(L.sf_sparse_conv_f32(
-                    x.data_ptr(), cp, rb['nbr'].data_ptr(), rb['stride'], rb['K'], k_first,
+                    x.data_ptr(), x.shape[0], cp, rb['nbr'].data_ptr(), rb['stride'], rb['K'], k_first,
                     lay.packed.data_ptr(), lay.cout, lay.scale.data_ptr(), lay.shift.data_ptr(),
                     res_ptr, 1 if lay.relu else 0, out.data_ptr(), c0 + 4 * rb['dst'],
                     self.sets[rb['dst']]['bound'], st))

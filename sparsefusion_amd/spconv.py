@@ -438,7 +438,7 @@ def sparse_conv(features, packed_filters, cin, cout, rulebook, scale=None, shift
             None, n_out, _lib.stream(features.device)))
         return _lib.forward_only(out, *grad_deps)
     _lib.check(L.sf_sparse_conv_f32(
-        _lib.ptr(x), cp, rulebook.nbr.data_ptr(), rulebook.nbr.shape[1], rulebook.K,
+        _lib.ptr(x), x.shape[0], cp, rulebook.nbr.data_ptr(), rulebook.nbr.shape[1], rulebook.K,
         rulebook.k_first, _lib.ptr(packed_filters), cout, _lib.ptr(scale), _lib.ptr(shift),
         _lib.ptr(residual), 1 if relu else 0, out.data_ptr(), None, n_out,
         _lib.stream(features.device)))
@@ -465,7 +465,7 @@ def indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_o
     x, cp = _padded_features(features, cin)
     out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
     k_first = (K - 1) // 2 if subm else -1
-    _lib.check(L.sf_sparse_conv_f32(_lib.ptr(x), cp, nbr.data_ptr(), stride_rows, K, k_first,
+    _lib.check(L.sf_sparse_conv_f32(_lib.ptr(x), x.shape[0], cp, nbr.data_ptr(), stride_rows, K, k_first,
                                     packed.data_ptr(), cout, None, None, None, 0, out.data_ptr(),
                                     None, n_out, _lib.stream(dev)))
     return _lib.forward_only(out, features, filters)

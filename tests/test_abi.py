@@ -48,10 +48,10 @@ def test_host_side_queries_and_errors():
     rc = L.sf_dynamic_voxelize(None, 10, 2, _lib.f3([1, 1, 1]), _lib.f6([0, 0, 0, 1, 1, 1]), None,
                                None)
     assert rc == -1 and b'f >= 3' in L.sf_last_error()
-    rc = L.sf_sparse_conv_f32(None, 7, None, 0, 27, -1, None, 16, None, None, None, 0, None, None, 0,
+    rc = L.sf_sparse_conv_f32(None, 0, 7, None, 0, 27, -1, None, 16, None, None, None, 0, None, None, 0,
                               None)
     assert rc == 0  # empty problem is a no-op
-    rc = L.sf_sparse_conv_f32(None, 16, None, 4, 64, -1, None, 16, None, None, None, 0, None, None,
+    rc = L.sf_sparse_conv_f32(None, 4, 16, None, 4, 64, -1, None, 16, None, None, None, 0, None, None,
                               4, None)
     assert rc == -1
 

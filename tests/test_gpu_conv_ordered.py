@@ -104,12 +104,54 @@ def test_ordered_conv_matches_oracle(dev, oracle, cin, cout, subm, ks, st, pd):
     torch.cuda.synchronize()
     assert_close(out.cpu().numpy(), expect)
     ref = torch.empty_like(out)
-    _lib.check(L.sf_sparse_conv_f32(d_feats.data_ptr(), cin, rb.nbr.data_ptr(), rb.nbr.shape[1], rb.K,
+    _lib.check(L.sf_sparse_conv_f32(d_feats.data_ptr(), n_in, cin, rb.nbr.data_ptr(), rb.nbr.shape[1], rb.K,
                                     rb.k_first, d_w.data_ptr(), cout, d_scale.data_ptr(),
                                     d_shift.data_ptr(), _lib.ptr(d_res), 1, ref.data_ptr(), None,
                                     n_out, _lib.stream(dev)))
     torch.cuda.synchronize()
     assert_close(out.cpu().numpy(), ref.cpu().numpy())
+
+
+@pytest.mark.parametrize('cin,cout,cap', [(64, 64, 1), (128, 128, 1), (64, 64, 3), (32, 32, 1)])
+def test_many_tiles_per_workgroup(dev, oracle, cin, cout, cap):
+    """The persistent workgroups walk their tiles in runs of 128 (kRun): small frames give every
+    workgroup one tile, a full-size frame two or three, so the second-run path is reached only with
+    the grid capped.  sf_debug_ordered_grid_cap (diagnostic hook) limits the grid to `cap`
+    workgroups: > 128 tiles each here; the result must not change."""
+    import ctypes
+    rng = np.random.default_rng(900 + cin)
+    coors = _coords(oracle, 61, 20000)
+    n = coors.shape[0]
+    assert (n + 63) // 64 > 128 * cap + 2, n
+    feats = rng.normal(0, 1, (n, cin)).astype(np.float32)
+    w = (rng.uniform(-1, 1, (27, cin, cout)) * np.sqrt(3.0 / (9 * cin))).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = rng.normal(0, 0.1, cout).astype(np.float32)
+    outids, pairs, num, _ = oracle.get_indice_pairs(coors, 1, SMALL_SHAPE, 3, 1, 1, 1, True)
+    expect = np.maximum(oracle.indice_conv(feats, w, pairs, num, n, True) * scale + shift, 0)
+    cs = spconv.CoordSet(to_dev(coors, dev), SMALL_SHAPE, 1)
+    rb = spconv.build_rulebook(cs, 3, 1, 1, 1, True)
+    L = _lib.lib()
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    raw.sf_debug_ordered_grid_cap.argtypes = [ctypes.c_int]
+    d_feats, d_w = to_dev(feats, dev), spconv.pack_filters(to_dev(w, dev))
+    d_scale, d_shift = to_dev(scale, dev), to_dev(shift, dev)
+    order = _row_order(rb, dev)
+    outs = []
+    for c in (0, cap):
+        out = torch.full((n, cout), np.nan, dtype=torch.float32, device=dev)
+        raw.sf_debug_ordered_grid_cap(c)
+        try:
+            _lib.check(L.sf_sparse_conv_f32_ordered(
+                d_feats.data_ptr(), n, cin, rb.nbr.data_ptr(), rb.nbr.shape[1], rb.K, rb.k_first,
+                order.data_ptr(), d_w.data_ptr(), cout, d_scale.data_ptr(), d_shift.data_ptr(), None,
+                1, out.data_ptr(), None, n, _lib.stream(dev)))
+            torch.cuda.synchronize()
+        finally:
+            raw.sf_debug_ordered_grid_cap(0)
+        outs.append(out.cpu().numpy())
+    assert_close(outs[1], expect.astype(np.float32))
+    assert np.array_equal(outs[0], outs[1])          # same sums in the same order, whatever the grid
 
 
 def test_pipeline_with_the_ordered_kernel(dev, oracle, monkeypatch):

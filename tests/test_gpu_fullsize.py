@@ -123,22 +123,53 @@ def test_nuscenes_frame_fp32(dev, oracle):
     assert int(np.count_nonzero(expect)) == g['bev_nonzero']
 
 
-def test_nuscenes_batch8_bf16(dev, oracle):
-    """BASELINE configs[2]: 8 distinct frames per batch on the bf16 path."""
+@pytest.fixture(scope='module')
+def batch8(oracle):
+    """The 8-frame batch of configs[2] through the fp32 oracle, once for both B = 8 tests (same
+    frames, same seeded weights: build(seed=1))."""
     cfg = configs.NUSC
     frames = [synth.nuscenes_frame(i) for i in range(8)]
+    ecfg = dict(cfg['pts_middle_encoder'])
+    ecfg.pop('type')
+    wcfg = {k: ecfg[k] for k in ('output_channels', 'encoder_channels', 'block_type')}
+    sd = synth.encoder_state_dict(1, ecfg['in_channels'], **wcfg)
+    vs, cs, ns = voxelize_oracle(oracle, cfg, frames)
+    coors4 = oracle.batch_coors(cs)
+    feats = np.concatenate([oracle.vfe_mean(v, n, 5) for v, n in zip(vs, ns)], 0)
+    expect = oracle.sparse_encoder_forward(sd, feats, coors4, 8, ecfg['sparse_shape'], 5,
+                                           encoder_paddings=ecfg['encoder_paddings'], **wcfg)
+    return dict(frames=frames, ns=ns, coors4=coors4, expect=expect)
+
+
+def test_nuscenes_batch8_fp32(dev, batch8):
+    """Eight full-size frames per batch on the fp32 path (`bench.py --batch 8 --dtype f32`): about
+    16 tiles per persistent workgroup in the 64- and 128-channel layers, 1.1 M rows at stage 2."""
+    cfg = configs.NUSC
+    frames = batch8['frames']
+    bb, sd, _, ecfg, okw = build(cfg, dev, 8, max(p.shape[0] for p in frames))
+    with torch.no_grad():
+        bev = bb([to_dev(p, dev) for p in frames]).clone()
+    res = bb.results()
+    assert res['overflow'] == 0
+    assert np.array_equal(res['coors'].cpu().numpy(), batch8['coors4'])
+    assert np.array_equal(res['num_points'].cpu().numpy(), np.concatenate(batch8['ns']))
+    assert gpu_rulebook_digests(bb) == fullsize_golden()['nusc_b8']
+    assert_close(bev.cpu().numpy(), batch8['expect'], 1e-4)
+
+
+def test_nuscenes_batch8_bf16(dev, oracle, batch8):
+    """BASELINE configs[2]: 8 distinct frames per batch on the bf16 path."""
+    cfg = configs.NUSC
+    frames = batch8['frames']
     bb, sd, _, ecfg, okw = build(cfg, dev, 8, max(p.shape[0] for p in frames), dtype='bf16')
     with torch.no_grad():
         bev = bb([to_dev(p, dev) for p in frames]).clone()
     res = bb.results()
     assert res['overflow'] == 0
-    vs, cs, ns = voxelize_oracle(oracle, cfg, frames)
-    coors4 = oracle.batch_coors(cs)
+    coors4, ns, expect = batch8['coors4'], batch8['ns'], batch8['expect']
     assert np.array_equal(res['coors'].cpu().numpy(), coors4)
     assert np.array_equal(res['num_points'].cpu().numpy(), np.concatenate(ns))
     assert gpu_rulebook_digests(bb) == fullsize_golden()['nusc_b8']
-    feats = np.concatenate([oracle.vfe_mean(v, n, 5) for v, n in zip(vs, ns)], 0)
-    expect = oracle.sparse_encoder_forward(sd, feats, coors4, 8, ecfg['sparse_shape'], 5, **okw)
     got = bev.cpu().numpy()
     assert got.shape == expect.shape == (8, 256, 180, 180)
     assert np.abs(got - expect).max() <= 5e-2 * np.abs(expect).max()

@@ -53,6 +53,54 @@ def test_static_entry_point_matches_workspace_entry_point(dev):
     assert ref[0] == 9000
 
 
+def test_static_entry_point_under_graph_capture_allocates_nothing(dev):
+    """The two claims of the header: the call can be CAPTURED in a HIP graph (after one eager call on
+    the device, which resolves the scratch symbol) and replayed on new buffer contents with the
+    results of sf_hard_voxelize, and it takes no device memory (hipMemGetInfo unchanged)."""
+    L = _lib.lib()
+    vl = configs.NUSC['pts_voxel_layer']
+    mp, mv, f = vl['max_num_points'], 20000, 5
+    frames = [np.ascontiguousarray(synth.nuscenes_frame(s)[:60000]) for s in (4, 5)]
+    n = frames[0].shape[0]
+    p = torch.from_numpy(frames[0]).to(dev)
+    voxels = torch.zeros((mv, mp, f), dtype=torch.float32, device=dev)
+    coors = torch.zeros((mv, 4), dtype=torch.int32, device=dev)
+    npv = torch.zeros((mv,), dtype=torch.int32, device=dev)
+    mean = torch.zeros((mv, 8), dtype=torch.float32, device=dev)
+    count = torch.zeros(2, dtype=torch.int32, device=dev)
+    args = (_lib.ptr(p), n, f, _lib.f3(vl['voxel_size']), _lib.f6(vl['point_cloud_range']), mp, mv,
+            voxels.data_ptr(), coors.data_ptr(), 4, 0, npv.data_ptr(), mean.data_ptr(), 5, 8,
+            count.data_ptr(), mv, count.data_ptr() + 4)
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        _lib.check(L.sf_hard_voxelize_static(*args, _lib.stream(dev)))      # eager warm-up call
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(dev)[0]
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            count.zero_()
+            _lib.check(L.sf_hard_voxelize_static(*args, _lib.stream(dev)))
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info(dev)[0] == free0          # nothing allocated, nothing freed
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        count.zero_()
+        _lib.check(L.sf_hard_voxelize_static(*args, _lib.stream(dev)))
+    assert torch.cuda.mem_get_info(dev)[0] <= free0
+    for pts in (frames[1], frames[0]):                        # replays on changed contents
+        p.copy_(torch.from_numpy(pts))
+        for t in (voxels, coors, npv, mean):
+            t.fill_(-7)
+        g.replay()
+        torch.cuda.synchronize()
+        got = (count.tolist(), voxels.cpu().numpy(), coors.cpu().numpy(), npv.cpu().numpy(),
+               mean.cpu().numpy())
+        m, ovf, *ref = run(L, dev, pts, vl, mv, static=False, batch_idx=0)
+        assert got[0] == [m, ovf] and m > 0
+        for a, b in zip(got[1:], ref):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
 def test_static_entry_point_rejects_oversized_input(dev):
     L = _lib.lib()
     vl = configs.WAYMO['pts_voxel_layer']

@@ -49,8 +49,8 @@ class Shim:
                     'c64' if cout <= 64 else 'c128')
 
         def conv(*a):
-            # sf_sparse_conv_f32(features_in, cin_padded, nbr, stride, K, k_first, w, cout, ...)
-            return 0 if group(a[1], a[7]) in skip else f(*a)
+            # sf_sparse_conv_f32(features_in, n_in, cin_padded, nbr, stride, K, k_first, w, cout, ...)
+            return 0 if group(a[2], a[8]) in skip else f(*a)
 
         def conv_ordered(*a):
             # sf_sparse_conv_f32_ordered(features_in, n_in, cin_padded, nbr, stride, K, k_first, order, w, cout, ...)

@@ -27,6 +27,10 @@ def main():
     ap.add_argument('--frames', type=int, default=40)
     ap.add_argument('--lanes', type=int, default=4)
     ap.add_argument('--distinct', type=int, default=4)
+    ap.add_argument('--wide-priority', type=int, default=None,
+                    help='create the wide-layer stream with this priority (-1 = high) instead of '
+                         'taking it from the probed pool')
+    ap.add_argument('--quiet', action='store_true', help='totals only')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     torch.cuda.set_device(dev)
@@ -34,8 +38,13 @@ def main():
     max_pts = max(p.shape[0] for p in host)
     cfg, ecfg, sd, enc, bb = bench.build_backbone('nusc', dev, 1, max_pts)
     lanes = [bb] + [LidarBackbone(cfg['pts_voxel_layer'], enc, dev, max_pts) for _ in range(args.lanes - 1)]
-    (l0, l1, wide), nq = concurrent_streams(dev, 3)
-    print('hardware queues found', nq)
+    if args.wide_priority is None:
+        (l0, l1, wide), nq = concurrent_streams(dev, 3)
+    else:
+        (l0, l1), nq = concurrent_streams(dev, 2)
+        wide = torch.cuda.Stream(device=dev, priority=args.wide_priority)
+        print('wide stream priority', wide.priority, 'range', torch.cuda.Stream.priority_range())
+    print('hardware queues found', nq, flush=True)
     frames = [[torch.from_numpy(p).to(dev)] for p in host]
     sfs = []
     with torch.no_grad():
@@ -84,6 +93,8 @@ def main():
         t2 = time.perf_counter()
         print(f'round {rnd}: host submit {1e3 * (t1 - t0):.2f} ms, all done {1e3 * (t2 - t0):.2f} ms '
               f'= {1e3 * (t2 - t0) / args.frames:.3f} ms/frame')
+    if args.quiet:
+        return
     print('frame: host submit [ms from t0] (wait_event, replay calls) | light seg GPU start..end | wide seg GPU start..end')
     for i, rec in enumerate(recs):
         parts = []

@@ -25,7 +25,7 @@ with torch.no_grad():
         rc = real(*a); torch.cuda.synchronize()
         raw.sf_debug_conv_profile(None)
         v = buf.cpu().numpy().astype(np.float64)
-        res.append((a[1], a[7], v.copy()))
+        res.append((a[2], a[8], v.copy()))
         return rc
     sh = Shim(); sh.__dict__['sf_sparse_conv_f32'] = wrapped
     bb.L = sh
