@@ -241,8 +241,8 @@ SF_API int sf_pack_filters_f32(const float *w_kio, int K, int cin, int cout, flo
  * i.e. eval-mode BatchNorm1d folded (make_sparse_convmodule, mmdet3d/ops/sparse_block.py:
  * 142-204) and the SparseBasicBlock tail (sparse_block.py:127-137).  scale/shift/residual may
  * be NULL (plain convolution).  features_in is (n_in_bound, cin_padded) f32 -- n_in_bound rows
- * must be addressable: the gathers are bounds checked against it, and the table must stay below
- * 2 GiB --; out (n_out, cout).
+ * must be addressable: the narrow-channel kernel bounds its gathers by it (tables of 2 GiB and
+ * more run on the general kernels) --; out (n_out, cout).
  * k_first >= 0 accumulates that offset first (the reference adds the SubM centre first). */
 SF_API int sf_sparse_conv_f32(const float *features_in, int n_in_bound, int cin_padded, const int *nbr,
                               int nbr_stride, int K, int k_first, const float *w_packed, int cout,

@@ -1178,13 +1178,15 @@ extern "C" int sf_sparse_conv_f32(const float *features_in, int n_in_bound, int 
                    ((uintptr_t)w_packed & 15) == 0 && ((uintptr_t)residual & 15) == 0 &&
                    ((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0,
                "feature / filter / epilogue pointers must be 16-byte aligned");
+  SF_CHECK_ARG(n_in_bound >= 1, "n_in_bound=%d: the input feature table must hold a row", n_in_bound);
+  // the narrow kernel gathers through a raw buffer bounded by the table size and marks a missing
+  // neighbour with offset 2^31: tables of 2 GiB and more stay on the general kernels (64-bit
+  // addresses)
   const long long feat_bytes = (long long)n_in_bound * cin_padded * 4;
-  SF_CHECK_ARG(n_in_bound >= 1 && feat_bytes < (1ll << 31),
-               "the input feature table (%d rows x %d channels) must hold a row and stay below 2 GiB",
-               n_in_bound, cin_padded);
-  ConvArgs a{features_in, (unsigned)feat_bytes, nbr, nbr_stride, K, k_first, w_packed, scale, shift,
-             residual, relu, out, n_out_dev, n_out_bound, st};
-  if (!env_legacy_narrow()) {  // the narrow 3x3x3 layers have a kernel of their own
+  const bool small_table = feat_bytes < (1ll << 31);
+  ConvArgs a{features_in, small_table ? (unsigned)feat_bytes : 0u, nbr, nbr_stride, K, k_first,
+             w_packed, scale, shift, residual, relu, out, n_out_dev, n_out_bound, st};
+  if (small_table && !env_legacy_narrow()) {  // the narrow 3x3x3 layers have a kernel of their own
     const int rc = sf_narrow_conv_f32(cin_padded, cout, a);
     if (rc <= 0) return rc;
   }

