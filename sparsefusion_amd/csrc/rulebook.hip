@@ -217,44 +217,95 @@ __global__ void nbr_fill_kernel(int *__restrict__ nbr, int nbr_stride, int k0, i
 }
 
 // SubMConv3d 3x3x3: if row o finds row i under offset k, then row i finds row o under offset
-// 26-k.  Each row probes the 13 offsets below the centre only (all 13 first probes in flight at
-// once), writes its own entry and scatters the mirrored one (columns 14..26 are pre-filled with
-// -1; atomicMin on the unsigned view keeps the first occurrence among duplicate coordinates).
+// 26-k.  Each row looks up the 13 offsets below the centre only, writes its own entry and scatters
+// the mirrored one (columns 14..26 are pre-filled with -1; atomicMin on the unsigned view keeps
+// the first occurrence among duplicate coordinates).
+// The 13 offsets are four x-triples (dz,dy) = (-1,-1) (-1,0) (-1,1) (0,-1) with dx = -1,0,1 and the
+// single (0,0,-1).  The three keys of a triple are consecutive integers, i.e. they sit in one or two
+// GROUPS of the coordinate hash (sf_group_slot): the kernel loads whole groups -- 16 bytes of keys,
+// one or two loads per triple, 7 on average per row instead of 13 probes -- and only the hits load a
+// value.  This is a random-access kernel: its floor is the number of L2 requests, not their bytes.
+// First-probe collisions (another group's key at the position) continue by single slots, all
+// pending offsets of a row together per round.
 __global__ void __launch_bounds__(kThreads)
 subm27_table_kernel(const int *__restrict__ outids, const int *n_dev, int n_bound, Geo g, int batch,
                     const uint32_t *__restrict__ keys, const int *__restrict__ vals, uint32_t mask,
                     int *__restrict__ nbr, int nbr_stride) {
   const int n = load_n(n_dev, n_bound);
+  const uint4 *__restrict__ keys4 = reinterpret_cast<const uint4 *>(keys);
+  const uint32_t gmask = mask >> 2;
   for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < n; o += gridDim.x * blockDim.x) {
     const int4 c = reinterpret_cast<const int4 *>(outids)[o];
     nbr[(size_t)13 * nbr_stride + o] = o;  // centre: every row pairs with itself
     const bool okb = c.x >= 0 && c.x < batch;
+    const bool okl = c.w >= 1, okh = c.w + 1 < g.ishape[2];
     uint32_t key[13], slot[13], kc[13];
-    int vc[13];
     bool ok[13];
+    // ---- group loads: all of them in flight before the first compare ------------------------
+    uint4 KA[5], KB[4];
+    uint32_t hA[5], hB[4];
+    bool two[4];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+      const int dz = t < 3 ? -1 : 0, dy = t < 3 ? t - 1 : (t == 3 ? -1 : 0);
+      const int iz = c.y + dz, iy = c.z + dy;
+      const bool okr = okb && iz >= 0 && iz < g.ishape[0] && iy >= 0 && iy < g.ishape[1];
+      const uint32_t kcen = lin_key(c.x, iz, iy, c.w, g.ishape);
+      if (t < 4) {
+        const uint32_t lo = okl ? kcen - 1u : kcen, hi = okh ? kcen + 1u : kcen;
+        hA[t] = sf_hash32(lo >> 2);
+        hB[t] = sf_hash32(hi >> 2);
+        two[t] = okr && (hi >> 2) != (lo >> 2);
+        KA[t] = okr ? keys4[hA[t] & gmask] : make_uint4(SF_EMPTY_KEY, SF_EMPTY_KEY, SF_EMPTY_KEY, SF_EMPTY_KEY);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          const int k = 3 * t + d;
+          key[k] = kcen + (uint32_t)d - 1u;
+          ok[k] = okr && (d == 0 ? okl : (d == 2 ? okh : true));
+        }
+      } else {
+        key[12] = kcen - 1u;
+        ok[12] = okr && okl;
+        hA[4] = sf_hash32(key[12] >> 2);
+        KA[4] = ok[12] ? keys4[hA[4] & gmask] : make_uint4(SF_EMPTY_KEY, SF_EMPTY_KEY, SF_EMPTY_KEY, SF_EMPTY_KEY);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) KB[t] = two[t] ? keys4[hB[t] & gmask] : KA[t];
+    // ---- first probe of every offset from the loaded groups ---------------------------------
+    auto pick = [](const uint4 &K, uint32_t p) {
+      return p == 0 ? K.x : (p == 1 ? K.y : (p == 2 ? K.z : K.w));
+    };
 #pragma unroll
     for (int k = 0; k < 13; ++k) {
-      const int iz = c.y + k / 9 - 1, iy = c.z + (k / 3) % 3 - 1, ix = c.w + k % 3 - 1;
-      ok[k] = okb && iz >= 0 && iz < g.ishape[0] && iy >= 0 && iy < g.ishape[1] && ix >= 0 &&
-              ix < g.ishape[2];
-      key[k] = lin_key(c.x, iz, iy, ix, g.ishape);
-      slot[k] = ok[k] ? sf_first_slot(key[k], mask) : 0u;
+      const int t = k < 12 ? k / 3 : 4;
+      bool inB = false;
+      if (t < 4) {
+        const uint32_t lo = okl ? key[3 * t + 1] - 1u : key[3 * t + 1];
+        inB = (key[k] >> 2) != (lo >> 2);
+      }
+      const uint32_t h = inB ? hB[t < 4 ? t : 0] : hA[t];
+      slot[k] = sf_group_slot(h, key[k], mask);
+      kc[k] = pick(inB ? KB[t < 4 ? t : 0] : KA[t], slot[k] & 3u);
     }
-#pragma unroll
-    for (int k = 0; k < 13; ++k) {  // 26 independent loads in flight
-      kc[k] = keys[slot[k]];
-      vc[k] = vals[slot[k]];
-    }
-    // resolve in rounds: every offset that still needs a probe issues it together with the
-    // others (one memory round trip per round, not per offset)
-    int res[13];
-    bool pend[13];
+    int res[13], vc[13];
+    bool pend[13], hit[13];
 #pragma unroll
     for (int k = 0; k < 13; ++k) {
-      res[k] = -1;
-      pend[k] = ok[k];
+      hit[k] = ok[k] && kc[k] == key[k];
+      pend[k] = ok[k] && !hit[k] && kc[k] != SF_EMPTY_KEY;
+      if (pend[k]) slot[k] = sf_next_slot(slot[k], mask);
     }
-    for (uint32_t round = 0; round <= mask; ++round) {
+    // one batch: the values of the hits and the next probe of the collisions
+#pragma unroll
+    for (int k = 0; k < 13; ++k)
+      if (hit[k] || pend[k]) vc[k] = vals[slot[k]];
+#pragma unroll
+    for (int k = 0; k < 13; ++k)
+      if (pend[k]) kc[k] = keys[slot[k]];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) res[k] = hit[k] ? vc[k] : -1;
+    for (uint32_t round = 0; round <= gmask; ++round) {
       bool more = false;
 #pragma unroll
       for (int k = 0; k < 13; ++k) {
@@ -265,7 +316,7 @@ subm27_table_kernel(const int *__restrict__ outids, const int *n_dev, int n_boun
           } else if (kc[k] == SF_EMPTY_KEY) {
             pend[k] = false;
           } else {
-            slot[k] = (slot[k] + 1) & mask;
+            slot[k] = sf_next_slot(slot[k], mask);
             more = true;
           }
         }

@@ -42,9 +42,7 @@ static inline int sf_div_up(long long a, long long b) { return (int)((a + b - 1)
 static inline int sf_grid(long long items, int threads) {
   long long b = (items + threads - 1) / threads;
   if (b < 1) b = 1;
-  static int cap = 0;
-  if (cap == 0) { const char *e = getenv("SF_GRID_CAP"); cap = e ? atoi(e) : 2048; if (cap < 1) cap = 2048; }
-  if (b > cap) b = cap;
+  if (b > 2048) b = 2048;
   return (int)b;
 }
 
@@ -104,25 +102,43 @@ __device__ __forceinline__ uint32_t sf_hash32(uint32_t k) {
   return k ^ (k >> 15);
 }
 
-// First probe slot: a scattering hash.  (A locality-preserving variant -- hash of the 16-cell x
-// block, low 4 bits kept so x neighbours share a 64-byte line -- was measured: primary
-// clustering and same-line atomic contention made inserts 2.7x and lookups 1.3x SLOWER.)
-__device__ __forceinline__ uint32_t sf_first_slot(uint32_t key, uint32_t mask) {
+// Scattering hash (the voxelizer's own slot table): first slot, then linear probing by one.
+__device__ __forceinline__ uint32_t sf_scatter_slot(uint32_t key, uint32_t mask) {
   return sf_hash32(key) & mask;
 }
 
+// Coordinate hash of the rulebooks.  Keys are linear cell indices ((b*D + z)*H + y)*W + x; the four
+// keys that share key >> 2 (four x neighbours of one (b, z, y) row whenever W % 4 == 0) share a
+// GROUP of four consecutive slots (16 bytes of the key array), so that the x - 1 / x / x + 1
+// neighbours of a cell are found with one or two 16-byte loads instead of three probes
+// (subm27_table_kernel).  slot = 4 * ((h + probe) & (groups - 1)) + ((key + (h >> 30)) & 3) with
+// h = hash(key >> 2): probing moves by whole groups and keeps the position inside the group, and
+// the position is rotated by two hash bits so that inputs whose keys are all congruent mod 4 still
+// use every slot.  (Round 1 measured a locality-preserving hash with probing by ONE slot: the
+// neighbours' slots then form the probe sequence, primary clustering, inserts 2.7x slower.)
+// capacity = mask + 1 is a power of two >= 4.
+__device__ __forceinline__ uint32_t sf_group_slot(uint32_t h, uint32_t key, uint32_t mask) {
+  return ((h & (mask >> 2)) << 2) | ((key + (h >> 30)) & 3u);
+}
+__device__ __forceinline__ uint32_t sf_first_slot(uint32_t key, uint32_t mask) {
+  return sf_group_slot(sf_hash32(key >> 2), key, mask);
+}
+__device__ __forceinline__ uint32_t sf_next_slot(uint32_t slot, uint32_t mask) {
+  return (slot + 4u) & mask;
+}
+
 // Insert `key` into an open-addressing table of `mask+1` slots; returns the slot that holds
-// the key, or -1 if the table is full (caller raises the overflow flag).
+// the key, or -1 if every slot the key may use is taken (caller raises the overflow flag).
 __device__ __forceinline__ int sf_hash_insert(uint32_t *keys, uint32_t mask, uint32_t key) {
   uint32_t slot = sf_first_slot(key, mask);
-  for (uint32_t probe = 0; probe <= mask; ++probe) {
+  for (uint32_t probe = 0; probe <= (mask >> 2); ++probe) {
     uint32_t cur = keys[slot];
     if (cur == key) return (int)slot;
     if (cur == SF_EMPTY_KEY) {
       uint32_t prev = atomicCAS(&keys[slot], SF_EMPTY_KEY, key);
       if (prev == SF_EMPTY_KEY || prev == key) return (int)slot;
     }
-    slot = (slot + 1) & mask;
+    slot = sf_next_slot(slot, mask);
   }
   return -1;
 }
@@ -131,11 +147,11 @@ __device__ __forceinline__ int sf_hash_insert(uint32_t *keys, uint32_t mask, uin
 __device__ __forceinline__ int sf_hash_find(const uint32_t *__restrict__ keys, uint32_t mask,
                                             uint32_t key) {
   uint32_t slot = sf_first_slot(key, mask);
-  for (uint32_t probe = 0; probe <= mask; ++probe) {
+  for (uint32_t probe = 0; probe <= (mask >> 2); ++probe) {
     uint32_t cur = keys[slot];
     if (cur == key) return (int)slot;
     if (cur == SF_EMPTY_KEY) return -1;
-    slot = (slot + 1) & mask;
+    slot = sf_next_slot(slot, mask);
   }
   return -1;
 }
@@ -146,12 +162,12 @@ __device__ __forceinline__ int sf_hash_lookup(const uint32_t *__restrict__ keys,
                                               const int *__restrict__ vals, uint32_t mask,
                                               uint32_t key) {
   uint32_t slot = sf_first_slot(key, mask);
-  for (uint32_t probe = 0; probe <= mask; ++probe) {
+  for (uint32_t probe = 0; probe <= (mask >> 2); ++probe) {
     uint32_t cur = keys[slot];
     int v = vals[slot];
     if (cur == key) return v;
     if (cur == SF_EMPTY_KEY) return -1;
-    slot = (slot + 1) & mask;
+    slot = sf_next_slot(slot, mask);
   }
   return -1;
 }

@@ -92,7 +92,7 @@ __global__ void vox_insert_kernel(const float *__restrict__ points, int n, int f
     }
     const uint32_t key = ((uint32_t)c[0] * (uint32_t)vp.grid[1] + (uint32_t)c[1]) *
                              (uint32_t)vp.grid[0] + (uint32_t)c[2];
-    uint32_t slot = sf_first_slot(key, mask);
+    uint32_t slot = sf_scatter_slot(key, mask);
     int found = -1;
     for (uint32_t probe = 0; probe <= mask; ++probe) {
       uint32_t cur = kf[2 * (size_t)slot];
@@ -202,7 +202,13 @@ vox_assign_kernel(int n, int max_points, int max_voxels, VoxParams vp, const int
   }
 }
 
-// second pass over the points: the lists of the surviving voxels
+// second pass over the points: the lists of the surviving voxels.
+// MP > 0: the list length is a compile-time constant and the WHOLE list is read at once (one round
+// trip instead of one per entry: the kernel's time is set by the crowded voxels, whose points walked
+// up to max_points dependent loads before their first atomic); the insert position is the number of
+// entries smaller than the point (entries only ever decrease, so a stale read can only start the
+// cascade too early, never too late).  MP == 0: any max_points, entry by entry.
+template <int MP>
 __global__ void vox_collect_kernel(int n, int max_points, const int *__restrict__ pslot,
                                    const int *__restrict__ slot_vid, const int *__restrict__ misc,
                                    int *__restrict__ lists) {
@@ -215,14 +221,28 @@ __global__ void vox_collect_kernel(int n, int max_points, const int *__restrict_
     if (vid < 0) continue;
     int *list = lists + (size_t)vid * max_points;
     int v = i;
-    // crowded voxels: once the list holds max_points smaller indices this point has no place in it
-    // (entries only ever decrease, so a stale read errs on the safe side)
-    if (__builtin_nontemporal_load(list + max_points - 1) < v) continue;
-    for (int s = 0; s < max_points; ++s) {
-      // a (possibly stale) smaller value means "not ours"
-      int cur = __builtin_nontemporal_load(list + s);
-      if (cur < v) continue;
-      if (cur == v) break;   // the voxel's first point: already in place (vox_assign)
+    int s0 = 0;
+    if constexpr (MP > 0) {
+      int e[MP];
+#pragma unroll
+      for (int s = 0; s < MP; ++s) e[s] = __builtin_nontemporal_load(list + s);
+      if (e[0] == v) continue;          // the voxel's first point: in place since vox_assign
+      int p = 0;
+#pragma unroll
+      for (int s = 0; s < MP; ++s) p += e[s] < v ? 1 : 0;
+      if (p >= MP) continue;            // the list already holds max_points smaller indices
+      s0 = p;
+    } else {
+      // crowded voxels: once the list holds max_points smaller indices this point has no place in it
+      if (__builtin_nontemporal_load(list + max_points - 1) < v) continue;
+    }
+    for (int s = s0; s < max_points; ++s) {
+      if constexpr (MP == 0) {
+        // a (possibly stale) smaller value means "not ours"
+        int cur = __builtin_nontemporal_load(list + s);
+        if (cur < v) continue;
+        if (cur == v) break;   // the voxel's first point: already in place (vox_assign)
+      }
       int old = atomicMin(list + s, v);
       if (old > v) v = old;  // we took the entry, carry the displaced value on
       if (v == SF_INT_MAX) break;
@@ -417,9 +437,13 @@ int hard_voxelize_impl(const float *points, int n, int f, const float voxel_size
                        (const int *)w.bsum, w.nblk, w.slot_vid, w.lists, coors, coors_stride,
                        batch_idx, rows_capacity, w.misc, row_count_dev, overflow_dev);
     SF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(vox_collect_kernel, dim3(sf_grid(n, kThreads)), dim3(kThreads), 0, st, n,
-                       max_points, (const int *)w.pslot, (const int *)w.slot_vid,
-                       (const int *)w.misc, w.lists);
+    auto collect = max_points == 10 ? vox_collect_kernel<10>
+                   : max_points == 5 ? vox_collect_kernel<5>
+                   : max_points <= 4 ? vox_collect_kernel<0> : vox_collect_kernel<0>;
+    if (max_points == 20) collect = vox_collect_kernel<20>;
+    if (max_points == 32) collect = vox_collect_kernel<32>;
+    hipLaunchKernelGGL(collect, dim3(sf_grid(n, kThreads)), dim3(kThreads), 0, st, n, max_points,
+                       (const int *)w.pslot, (const int *)w.slot_vid, (const int *)w.misc, w.lists);
     SF_CHECK_LAUNCH();
     long long bound_v = (max_voxels >= 0 && max_voxels < n) ? max_voxels : n;
     if (voxels) {
