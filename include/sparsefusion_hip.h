@@ -222,6 +222,67 @@ SF_API int sf_export_indice_pairs(const int *nbr, int nbr_stride, int K, const i
 SF_API int sf_indice_pairs_to_table(const int *indice_pairs, const int *indice_num, int K, int L,
                                     int n_out, int *nbr, int nbr_stride, void *stream);
 
+/* ---- the coordinate phase of a frame in one call (csrc/front.hip) -------------------- */
+
+/* One coordinate set of the encoder: the voxels (set 0) or the output rows of a strided layer. */
+typedef struct SfCoordSet {
+  int shape[3];      /* spatial shape (D, H, W) */
+  int bound;         /* rows `indices` holds (host bound on the row count) */
+  int *indices;      /* (bound, 4) i32 (b,z,y,x) */
+  uint32_t *keys;    /* coordinate hash: `capacity` keys ... */
+  int *vals;         /* ... and values (sf_hash_capacity(bound) slots) */
+  int capacity;
+} SfCoordSet;
+
+/* One rulebook: a SubM layer geometry on a set (dst == src) or a strided one between two sets. */
+typedef struct SfRulebook {
+  int src, dst;      /* indices into SfFrontDesc.sets */
+  int ksize[3], stride[3], padding[3];
+  int subm;
+  int *nbr;          /* (K, nbr_stride) neighbour table, nbr_stride >= sets[dst].bound */
+  int nbr_stride;
+  int *plan;         /* sf_row_order_by_mask plan of the table (sf_row_order_size ints) or NULL */
+  void *plan_ws;     /* its workspace (sf_row_order_workspace bytes) */
+  size_t plan_ws_bytes;
+  int *first;        /* strided only: sets[dst].capacity ints of scratch of this rulebook */
+} SfRulebook;
+
+typedef struct SfFrontDesc {
+  /* voxelizer (arguments of sf_hard_voxelize, one point cloud per sample) */
+  int batch;
+  const float *const *points;   /* host array of `batch` device pointers, (n_b, num_features) f32 */
+  const int *num_points;        /* host array of `batch` point counts */
+  int num_features;
+  float voxel_size[3], coors_range[6];
+  int max_points, max_voxels;
+  float *voxels;                /* (sets[0].bound, max_points, num_features) or NULL */
+  int *num_points_per_voxel;    /* (sets[0].bound) or NULL */
+  float *mean;                  /* (sets[0].bound, mean_stride) or NULL */
+  int mean_features, mean_stride;
+  void *vox_workspace;          /* batch * vox_workspace_bytes bytes, a slice per sample ... */
+  size_t vox_workspace_bytes;   /* ... of sf_hard_voxelize_workspace(max n_b, max_points) bytes */
+  /* coordinate sets and rulebooks of the encoder */
+  int n_sets;
+  const SfCoordSet *sets;
+  int *counts_dev;              /* n_sets + 1 device ints: row count per set, then the overflow flag */
+  int n_rulebooks;
+  const SfRulebook *rulebooks;  /* in layer order */
+  void *rb_workspace;           /* max over the strided rulebooks of sf_strided_rulebook_workspace */
+  size_t rb_workspace_bytes;
+} SfFrontDesc;
+
+/* Voxelizer + coordinate hashes + every rulebook + the plans of the mask-ordered layers of one
+ * batch, enqueued by one call: what SparseFusionDetector.voxelize (detectors/sparsefusion.py:
+ * 133-161) and the get_indice_pairs of every sparse convolution of SparseEncoder.forward
+ * (ops/spconv/conv.py:113-204 -> spconv_ops.h:27-141) compute.  Same kernels and bit-identical
+ * buffers as the sequence sf_hard_voxelize (per sample, rows appended, coors_stride 4) ->
+ * sf_hash_build -> sf_neighbor_table / sf_strided_rulebook (-> sf_row_order_by_mask) per rulebook,
+ * with fewer launches: one fill kernel for all tables, row assignments that open the table entries
+ * of their rows, the table scatter of a strided rulebook in one launch with the SubM table of its
+ * output set.  The descriptor is read during the call only (host memory; device pointers inside).
+ * counts_dev is zeroed by the call. */
+SF_API int sf_lidar_front(const SfFrontDesc *desc, void *stream);
+
 /* ------------------------------------------------------------------ convolution ------ */
 
 /* Channel count a feature matrix must be padded to as conv INPUT (8, 16, 32, 64 or 128), or

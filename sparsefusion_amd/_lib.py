@@ -20,6 +20,30 @@ _F3, _F6, _I3 = C.c_float * 3, C.c_float * 6, C.c_int * 3   # array instances de
 _f3 = _f6 = C.POINTER(C.c_float)
 _i3 = C.POINTER(C.c_int)
 
+
+class SfCoordSet(C.Structure):
+    _fields_ = [('shape', C.c_int * 3), ('bound', C.c_int), ('indices', C.c_void_p),
+                ('keys', C.c_void_p), ('vals', C.c_void_p), ('capacity', C.c_int)]
+
+
+class SfRulebook(C.Structure):
+    _fields_ = [('src', C.c_int), ('dst', C.c_int), ('ksize', C.c_int * 3), ('stride', C.c_int * 3),
+                ('padding', C.c_int * 3), ('subm', C.c_int), ('nbr', C.c_void_p),
+                ('nbr_stride', C.c_int), ('plan', C.c_void_p), ('plan_ws', C.c_void_p),
+                ('plan_ws_bytes', C.c_size_t), ('first', C.c_void_p)]
+
+
+class SfFrontDesc(C.Structure):
+    _fields_ = [('batch', C.c_int), ('points', C.POINTER(C.c_void_p)), ('num_points', C.POINTER(C.c_int)),
+                ('num_features', C.c_int), ('voxel_size', C.c_float * 3), ('coors_range', C.c_float * 6),
+                ('max_points', C.c_int), ('max_voxels', C.c_int), ('voxels', C.c_void_p),
+                ('num_points_per_voxel', C.c_void_p), ('mean', C.c_void_p), ('mean_features', C.c_int),
+                ('mean_stride', C.c_int), ('vox_workspace', C.c_void_p), ('vox_workspace_bytes', C.c_size_t),
+                ('n_sets', C.c_int), ('sets', C.POINTER(SfCoordSet)), ('counts_dev', C.c_void_p),
+                ('n_rulebooks', C.c_int), ('rulebooks', C.POINTER(SfRulebook)),
+                ('rb_workspace', C.c_void_p), ('rb_workspace_bytes', C.c_size_t)]
+
+
 # name -> (restype, argtypes); kept in step with include/sparsefusion_hip.h (tests check it)
 SIGNATURES = {
     'sf_version': (_i, []),
@@ -47,6 +71,7 @@ SIGNATURES = {
     'sf_export_indice_pairs_workspace': (_sz, [_i, _i]),
     'sf_export_indice_pairs': (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     'sf_indice_pairs_to_table': (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp]),
+    'sf_lidar_front': (_i, [C.POINTER(SfFrontDesc), _vp]),
     'sf_conv_padded_cin': (_i, [_i]),
     'sf_pack_filters_f32': (_i, [_vp, _i, _i, _i, _vp, _vp]),
     'sf_sparse_conv_f32': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp,

@@ -6,7 +6,9 @@
 // the active count, and the rulebook is kept OUTPUT-major ("neighbour table"): for every output
 // row and kernel offset the input row or -1.  That is the form the output-stationary
 // convolution kernel consumes; sf_export_indice_pairs converts it to the reference's tensors.
-#include "sf_common.h"
+#include <string.h>
+
+#include "front_internal.h"
 
 namespace {
 
@@ -216,6 +218,35 @@ __global__ void nbr_fill_kernel(int *__restrict__ nbr, int nbr_stride, int k0, i
   for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < n; o += gridDim.x * blockDim.x) col[o] = -1;
 }
 
+// the same for two tables on the same rows in one launch (blockIdx.y runs over a's columns, then b's)
+__global__ void nbr_fill2_kernel(SfNbrPrefill a, SfNbrPrefill b, const int *n_dev, int n_bound) {
+  const int n = load_n(n_dev, n_bound);
+  const int ya = a.k1 - a.k0;
+  const bool second = (int)blockIdx.y >= ya;
+  const SfNbrPrefill &t = second ? b : a;
+  const int k = t.k0 + (int)blockIdx.y - (second ? ya : 0);
+  if (k >= t.k1) return;
+  int *__restrict__ col = t.nbr + (size_t)k * t.stride;
+  for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < n; o += gridDim.x * blockDim.x) col[o] = -1;
+}
+
+// hash_build_kernel + the fill of a table on the same rows (the set's SubM table) in one launch
+__global__ void hash_build_fill_kernel(const int *__restrict__ indices, const int *n_dev, int n_bound,
+                                       Geo g, uint32_t *__restrict__ keys, int *__restrict__ vals,
+                                       uint32_t mask, int *overflow_dev, SfNbrPrefill pf) {
+  const int n = load_n(n_dev, n_bound);
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    int4 c = reinterpret_cast<const int4 *>(indices)[j];
+    for (int k = pf.k0; k < pf.k1; ++k) pf.nbr[(size_t)k * pf.stride + j] = -1;
+    int slot = sf_hash_insert(keys, mask, lin_key(c.x, c.y, c.z, c.w, g.ishape));
+    if (slot < 0) {
+      if (overflow_dev) *overflow_dev = 1;
+      continue;
+    }
+    atomicMin(&vals[slot], j);  // first occurrence wins for duplicate coordinates
+  }
+}
+
 // SubMConv3d 3x3x3: if row o finds row i under offset k, then row i finds row o under offset
 // 26-k.  Each row looks up the 13 offsets below the centre only, writes its own entry and scatters
 // the mirrored one (columns 14..26 are pre-filled with -1; atomicMin on the unsigned view keeps
@@ -227,14 +258,14 @@ __global__ void nbr_fill_kernel(int *__restrict__ nbr, int nbr_stride, int k0, i
 // value.  This is a random-access kernel: its floor is the number of L2 requests, not their bytes.
 // First-probe collisions (another group's key at the position) continue by single slots, all
 // pending offsets of a row together per round.
-__global__ void __launch_bounds__(kThreads)
-subm27_table_kernel(const int *__restrict__ outids, const int *n_dev, int n_bound, Geo g, int batch,
-                    const uint32_t *__restrict__ keys, const int *__restrict__ vals, uint32_t mask,
-                    int *__restrict__ nbr, int nbr_stride) {
+__device__ __forceinline__ void
+subm27_body(int block, int nblocks, const int *__restrict__ outids, const int *n_dev, int n_bound,
+            const Geo &g, int batch, const uint32_t *__restrict__ keys, const int *__restrict__ vals,
+            uint32_t mask, int *__restrict__ nbr, int nbr_stride) {
   const int n = load_n(n_dev, n_bound);
   const uint4 *__restrict__ keys4 = reinterpret_cast<const uint4 *>(keys);
   const uint32_t gmask = mask >> 2;
-  for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < n; o += gridDim.x * blockDim.x) {
+  for (int o = block * blockDim.x + threadIdx.x; o < n; o += nblocks * blockDim.x) {
     const int4 c = reinterpret_cast<const int4 *>(outids)[o];
     nbr[(size_t)13 * nbr_stride + o] = o;  // centre: every row pairs with itself
     const bool okb = c.x >= 0 && c.x < batch;
@@ -338,6 +369,14 @@ subm27_table_kernel(const int *__restrict__ outids, const int *n_dev, int n_boun
                   (unsigned)o);
     }
   }
+}
+
+__global__ void __launch_bounds__(kThreads)
+subm27_table_kernel(const int *__restrict__ outids, const int *n_dev, int n_bound, Geo g, int batch,
+                    const uint32_t *__restrict__ keys, const int *__restrict__ vals, uint32_t mask,
+                    int *__restrict__ nbr, int nbr_stride) {
+  subm27_body(blockIdx.x, gridDim.x, outids, n_dev, n_bound, g, batch, keys, vals, mask, nbr,
+              nbr_stride);
 }
 
 // Strided rulebook, input side.  Every input remembers the table slots of the outputs it reaches
@@ -515,12 +554,12 @@ outset_count27_kernel(const int *__restrict__ indices, const int *n_dev, int n_b
   if (threadIdx.x == 0) bsum[blockIdx.x] = total;
 }
 
-__global__ void __launch_bounds__(kThreads)
-outset_scatter27_kernel(const int *__restrict__ indices, const int *n_dev, int n_bound, Geo g,
-                        const int *__restrict__ slots, const int *__restrict__ vals,
-                        int *__restrict__ nbr, int nbr_stride, int nbr_rows) {
+__device__ __forceinline__ void
+scatter27_body(int block, int nblocks, const int *__restrict__ indices, const int *n_dev, int n_bound,
+               const Geo &g, const int *__restrict__ slots, const int *__restrict__ vals,
+               int *__restrict__ nbr, int nbr_stride, int nbr_rows) {
   const int n = load_n(n_dev, n_bound);
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+  for (int j = block * blockDim.x + threadIdx.x; j < n; j += nblocks * blockDim.x) {
     const int4 c = reinterpret_cast<const int4 *>(indices)[j];
     bool ok[27];
     int kidx[27], ord[27], sl[27], orow[27];
@@ -537,6 +576,41 @@ outset_scatter27_kernel(const int *__restrict__ indices, const int *n_dev, int n
                   (unsigned)j);
   }
 }
+
+__global__ void __launch_bounds__(kThreads)
+outset_scatter27_kernel(const int *__restrict__ indices, const int *n_dev, int n_bound, Geo g,
+                        const int *__restrict__ slots, const int *__restrict__ vals,
+                        int *__restrict__ nbr, int nbr_stride, int nbr_rows) {
+  scatter27_body(blockIdx.x, gridDim.x, indices, n_dev, n_bound, g, slots, vals, nbr, nbr_stride,
+                 nbr_rows);
+}
+
+// The table scatter of a strided rulebook and the SubM table of its OUTPUT set depend on the same
+// predecessor (the row assignment) and on nothing of each other: one launch, the first
+// `scatter_blocks` workgroups scatter, the rest look neighbours up -- two latency-bound kernels
+// side by side instead of one behind the other.
+struct ScatterArgs {
+  const int *indices, *n_dev;
+  int n_bound;
+  Geo g;
+  const int *slots, *vals;
+  int *nbr;
+  int nbr_stride, nbr_rows;
+};
+__global__ void __launch_bounds__(kThreads)
+scatter27_subm27_kernel(ScatterArgs sa, int scatter_blocks, const int *__restrict__ outids,
+                        const int *n_dev, int n_bound, Geo g, int batch,
+                        const uint32_t *__restrict__ keys, const int *__restrict__ vals, uint32_t mask,
+                        int *__restrict__ nbr, int nbr_stride) {
+  if ((int)blockIdx.x < scatter_blocks)
+    scatter27_body(blockIdx.x, scatter_blocks, sa.indices, sa.n_dev, sa.n_bound, sa.g, sa.slots, sa.vals,
+                   sa.nbr, sa.nbr_stride, sa.nbr_rows);
+  else
+    subm27_body(blockIdx.x - scatter_blocks, gridDim.x - scatter_blocks, outids, n_dev, n_bound, g,
+                batch, keys, vals, mask, nbr, nbr_stride);
+}
+
+static_assert(sizeof(Geo) <= sizeof(((SfScatterJob *)0)->geo), "SfScatterJob::geo too small");
 
 // ---- export to the reference's (K,2,L) pair lists ------------------------------------
 __global__ void fill_int_kernel(int *__restrict__ p, long long n, int v) {
@@ -656,7 +730,13 @@ extern "C" int sf_hash_capacity(long long n_bound) {
 extern "C" int sf_hash_build(const int *indices, const int *n_dev, int n_bound, const int shape[3],
                              int batch, uint32_t *keys, int *vals, int capacity, int *overflow_dev,
                              void *stream) {
-  hipStream_t st = (hipStream_t)stream;
+  return sf_int_hash_build(indices, n_dev, n_bound, shape, batch, keys, vals, capacity, overflow_dev, 0,
+                           SfNbrPrefill{nullptr, 0, 0, 0}, (hipStream_t)stream);
+}
+
+int sf_int_hash_build(const int *indices, const int *n_dev, int n_bound, const int shape[3], int batch,
+                      uint32_t *keys, int *vals, int capacity, int *overflow_dev, int keys_ready,
+                      SfNbrPrefill pf, hipStream_t st) {
   SF_CHECK_ARG(n_bound >= 0 && batch >= 1 && shape, "bad n_bound/batch/shape");
   SF_CHECK_ARG(keys && vals && is_pow2(capacity) && capacity >= n_bound,
                "hash table NULL or capacity %d not a power of two >= n_bound %d", capacity,
@@ -666,13 +746,20 @@ extern "C" int sf_hash_build(const int *indices, const int *n_dev, int n_bound, 
   const int one[3] = {1, 1, 1}, zero[3] = {0, 0, 0};
   int rc = make_geo(shape, nullptr, one, one, zero, batch, &g);
   if (rc != SF_OK) return rc;
-  hipLaunchKernelGGL(table_fill_kernel, dim3(sf_grid(capacity, kThreads)), dim3(kThreads), 0, st,
-                     keys, vals, capacity, (int *)nullptr, 0, 0);
-  SF_CHECK_LAUNCH();
+  if (!keys_ready) {
+    hipLaunchKernelGGL(table_fill_kernel, dim3(sf_grid(capacity, kThreads)), dim3(kThreads), 0, st,
+                       keys, vals, capacity, (int *)nullptr, 0, 0);
+    SF_CHECK_LAUNCH();
+  }
   if (n_bound > 0) {
-    hipLaunchKernelGGL(hash_build_kernel, dim3(sf_grid(n_bound, kThreads)), dim3(kThreads), 0, st,
-                       indices, n_dev, n_bound, g, keys, vals, (uint32_t)(capacity - 1),
-                       overflow_dev);
+    if (pf.nbr && pf.k1 > pf.k0)
+      hipLaunchKernelGGL(hash_build_fill_kernel, dim3(sf_grid(n_bound, kThreads)), dim3(kThreads), 0, st,
+                         indices, n_dev, n_bound, g, keys, vals, (uint32_t)(capacity - 1), overflow_dev,
+                         pf);
+    else
+      hipLaunchKernelGGL(hash_build_kernel, dim3(sf_grid(n_bound, kThreads)), dim3(kThreads), 0, st,
+                         indices, n_dev, n_bound, g, keys, vals, (uint32_t)(capacity - 1),
+                         overflow_dev);
     SF_CHECK_LAUNCH();
   }
   return SF_OK;
@@ -745,13 +832,13 @@ extern "C" size_t sf_strided_rulebook_workspace(int n_bound, int out_capacity, c
          align_up(nb * 4 * (size_t)conv_reach(ksize, stride));
 }
 
-extern "C" int sf_strided_rulebook(const int *indices, const int *n_dev, int n_bound, int batch,
-                                   const int out_shape[3], const int ksize[3], const int stride[3],
-                                   const int padding[3], uint32_t *out_keys, int *out_vals,
-                                   int out_capacity, int *outids, int outids_rows, int *n_out_dev,
-                                   int *overflow_dev, int *nbr, int nbr_stride, void *workspace,
-                                   size_t workspace_bytes, void *stream) {
-  hipStream_t st = (hipStream_t)stream;
+int sf_int_strided_rulebook(const int *indices, const int *n_dev, int n_bound, int batch,
+                            const int out_shape[3], const int ksize[3], const int stride[3],
+                            const int padding[3], uint32_t *out_keys, int *out_vals,
+                            int out_capacity, int *outids, int outids_rows, int *n_out_dev,
+                            int *overflow_dev, int *nbr, int nbr_stride, void *workspace,
+                            size_t workspace_bytes, hipStream_t st, const SfStridedFuse *fuse,
+                            SfScatterJob *job) {
   SF_CHECK_ARG(n_bound >= 0 && batch >= 1 && out_shape, "bad n_bound/batch/out_shape");
   SF_CHECK_ARG(out_keys && out_vals && is_pow2(out_capacity), "output table NULL or capacity %d "
                "not a power of two", out_capacity);
@@ -769,15 +856,19 @@ extern "C" int sf_strided_rulebook(const int *indices, const int *n_dev, int n_b
     sf_set_error("workspace too small: %zu < %zu bytes", workspace_bytes, need);
     return SF_ERR_WORKSPACE;
   }
-  int *first = (int *)workspace;
+  int *first = (fuse && fuse->first) ? fuse->first : (int *)workspace;
   int *bsum = (int *)((char *)workspace + align_up((size_t)out_capacity * 4));
   const int nblk = sf_div_up(n_bound > 0 ? n_bound : 1, kChunk);
   unsigned *ftmask = (unsigned *)((char *)bsum + align_up((size_t)nblk * 4));
   int *slots = (int *)((char *)workspace + sf_conv_output_set_workspace(n_bound, out_capacity));
   const uint32_t mask = (uint32_t)(out_capacity - 1);
-  hipLaunchKernelGGL(table_fill_kernel, dim3(sf_grid(out_capacity, kThreads)), dim3(kThreads), 0,
-                     st, out_keys, first, out_capacity, out_vals, out_capacity, -1);
-  SF_CHECK_LAUNCH();
+  if (!(fuse && fuse->tables_ready)) {
+    // (the values need no fill: every slot a later kernel reads was given its row, or -1, by the
+    // assign pass)
+    hipLaunchKernelGGL(table_fill_kernel, dim3(sf_grid(out_capacity, kThreads)), dim3(kThreads), 0,
+                       st, out_keys, first, out_capacity, (int *)nullptr, 0, -1);
+    SF_CHECK_LAUNCH();
+  }
   const bool small = ksize[0] <= 3 && ksize[1] <= 3 && ksize[2] <= 3;  // batched-probe kernels
   // (a batched-probe insert -- all candidates' reads, then all claims, in rounds -- measured
   // SLOWER than the sequential one, 50 vs 34 us: most inserts find their key already present on
@@ -796,22 +887,101 @@ extern "C" int sf_strided_rulebook(const int *indices, const int *n_dev, int n_b
                      n_bound, g, (const int *)slots, (const unsigned *)ftmask, (const int *)bsum,
                      nblk, out_vals, outids, outids_rows, n_out_dev, overflow_dev);
   SF_CHECK_LAUNCH();
-  if (outids_rows > 0) {
+  if (outids_rows > 0) {   // -1 for the rows in use: this table and, in the same launch, a later one
+    SfNbrPrefill pf_next = {};
+    if (fuse && fuse->pf_next.nbr) pf_next = fuse->pf_next;
     int gx = sf_div_up(outids_rows, kThreads);
     if (gx > 1024) gx = 1024;
-    hipLaunchKernelGGL(nbr_fill_kernel, dim3(gx, g.K), dim3(kThreads), 0, st, nbr, nbr_stride, 0,
-                       g.K, (const int *)n_out_dev, outids_rows);
-    SF_CHECK_LAUNCH();
-    if (small)
-      hipLaunchKernelGGL(outset_scatter27_kernel, dim3(sf_grid(n_bound, kThreads)), dim3(kThreads),
-                         0, st, indices, n_dev, n_bound, g, (const int *)slots,
-                         (const int *)out_vals, nbr, nbr_stride, outids_rows);
-    else
-      hipLaunchKernelGGL(outset_scatter_table_kernel, dim3(sf_grid(n_bound, kThreads)),
-                         dim3(kThreads), 0, st, indices, n_dev, n_bound, g, (const int *)slots,
-                         (const int *)out_vals, nbr, nbr_stride, outids_rows);
+    hipLaunchKernelGGL(nbr_fill2_kernel, dim3(gx, g.K + (pf_next.k1 - pf_next.k0)), dim3(kThreads), 0, st,
+                       SfNbrPrefill{nbr, nbr_stride, 0, g.K}, pf_next, (const int *)n_out_dev, outids_rows);
     SF_CHECK_LAUNCH();
   }
+  SfScatterJob j = {};
+  j.indices = indices;
+  j.n_dev = n_dev;
+  j.n_bound = n_bound;
+  memcpy(j.geo, &g, sizeof(Geo));
+  j.slots = slots;
+  j.vals = out_vals;
+  j.nbr = nbr;
+  j.nbr_stride = nbr_stride;
+  j.nbr_rows = outids_rows;
+  j.small = small ? 1 : 0;
+  if (fuse && fuse->defer_scatter && job) {
+    *job = j;
+    return SF_OK;
+  }
+  return sf_int_scatter(&j, st);
+}
+
+int sf_int_scatter(const SfScatterJob *job, hipStream_t st) {
+  if (job->nbr_rows <= 0 || job->n_bound <= 0) return SF_OK;
+  Geo g;
+  memcpy(&g, job->geo, sizeof(Geo));
+  if (job->small)
+    hipLaunchKernelGGL(outset_scatter27_kernel, dim3(sf_grid(job->n_bound, kThreads)), dim3(kThreads),
+                       0, st, job->indices, job->n_dev, job->n_bound, g, job->slots, job->vals,
+                       job->nbr, job->nbr_stride, job->nbr_rows);
+  else
+    hipLaunchKernelGGL(outset_scatter_table_kernel, dim3(sf_grid(job->n_bound, kThreads)),
+                       dim3(kThreads), 0, st, job->indices, job->n_dev, job->n_bound, g, job->slots,
+                       job->vals, job->nbr, job->nbr_stride, job->nbr_rows);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+extern "C" int sf_strided_rulebook(const int *indices, const int *n_dev, int n_bound, int batch,
+                                   const int out_shape[3], const int ksize[3], const int stride[3],
+                                   const int padding[3], uint32_t *out_keys, int *out_vals,
+                                   int out_capacity, int *outids, int outids_rows, int *n_out_dev,
+                                   int *overflow_dev, int *nbr, int nbr_stride, void *workspace,
+                                   size_t workspace_bytes, void *stream) {
+  return sf_int_strided_rulebook(indices, n_dev, n_bound, batch, out_shape, ksize, stride, padding,
+                                 out_keys, out_vals, out_capacity, outids, outids_rows, n_out_dev,
+                                 overflow_dev, nbr, nbr_stride, workspace, workspace_bytes,
+                                 (hipStream_t)stream, nullptr, nullptr);
+}
+
+int sf_int_subm27(const int *outids, const int *n_dev, int n_bound, int batch, const int in_shape[3],
+                  const uint32_t *keys, const int *vals, int capacity, int *nbr, int nbr_stride,
+                  int prefilled, const SfScatterJob *job, hipStream_t st) {
+  Geo g;
+  const int three[3] = {3, 3, 3}, one[3] = {1, 1, 1};
+  int rc = make_geo(in_shape, nullptr, three, one, one, batch, &g);
+  if (rc != SF_OK) return rc;
+  int gx = sf_div_up(n_bound, kThreads);
+  if (gx > 4096) gx = 4096;
+  if (gx < 1) gx = 1;
+  if (!prefilled) {
+    hipLaunchKernelGGL(nbr_fill_kernel, dim3(gx > 1024 ? 1024 : gx, 13), dim3(kThreads), 0, st, nbr,
+                       nbr_stride, 14, 27, n_dev, n_bound);
+    SF_CHECK_LAUNCH();
+  }
+  const uint32_t mask = (uint32_t)(capacity - 1);
+  if (job && job->small && job->nbr_rows > 0 && job->n_bound > 0) {
+    ScatterArgs sa;
+    sa.indices = job->indices;
+    sa.n_dev = job->n_dev;
+    sa.n_bound = job->n_bound;
+    memcpy(&sa.g, job->geo, sizeof(Geo));
+    sa.slots = job->slots;
+    sa.vals = job->vals;
+    sa.nbr = job->nbr;
+    sa.nbr_stride = job->nbr_stride;
+    sa.nbr_rows = job->nbr_rows;
+    const int sb = sf_grid(job->n_bound, kThreads);
+    hipLaunchKernelGGL(scatter27_subm27_kernel, dim3(sb + gx), dim3(kThreads), 0, st, sa, sb, outids,
+                       n_dev, n_bound, g, batch, keys, vals, mask, nbr, nbr_stride);
+    SF_CHECK_LAUNCH();
+    return SF_OK;
+  }
+  if (job) {
+    rc = sf_int_scatter(job, st);
+    if (rc != SF_OK) return rc;
+  }
+  hipLaunchKernelGGL(subm27_table_kernel, dim3(gx), dim3(kThreads), 0, st, outids, n_dev, n_bound, g,
+                     batch, keys, vals, mask, nbr, nbr_stride);
+  SF_CHECK_LAUNCH();
   return SF_OK;
 }
 
@@ -835,16 +1005,8 @@ extern "C" int sf_neighbor_table(const int *outids, const int *n_out_dev, int n_
   if (identity_center && g.K == 27 && ksize[0] == 3 && ksize[1] == 3 && stride[0] == 1 &&
       stride[1] == 1 && stride[2] == 1 && padding[0] == 1 && padding[1] == 1 && padding[2] == 1) {
     // SubMConv3d 3x3x3: half the probes, the other half mirrored (subm27_table_kernel)
-    int gx = sf_div_up(n_out_bound, kThreads);
-    if (gx > 4096) gx = 4096;
-    hipLaunchKernelGGL(nbr_fill_kernel, dim3(gx > 1024 ? 1024 : gx, 13), dim3(kThreads), 0, st, nbr,
-                       nbr_stride, 14, 27, n_out_dev, n_out_bound);
-    SF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(subm27_table_kernel, dim3(gx), dim3(kThreads), 0, st, outids, n_out_dev,
-                       n_out_bound, g, batch, in_keys, in_vals, (uint32_t)(in_capacity - 1), nbr,
-                       nbr_stride);
-    SF_CHECK_LAUNCH();
-    return SF_OK;
+    return sf_int_subm27(outids, n_out_dev, n_out_bound, batch, in_shape, in_keys, in_vals,
+                         in_capacity, nbr, nbr_stride, 0, nullptr, st);
   }
   // lookup chains are latency-bound: one (offset, row) per thread where the bound allows it
   int nt_x = sf_div_up(n_out_bound, kThreads);

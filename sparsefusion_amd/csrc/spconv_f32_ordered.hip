@@ -31,7 +31,7 @@
 // -- fixed, no atomics, independent of the row order.
 #include <stdlib.h>
 
-#include "sf_common.h"
+#include "front_internal.h"
 
 namespace {
 
@@ -980,7 +980,22 @@ extern "C" int sf_row_order_size(int n_bound) {
 extern "C" int sf_row_order_by_mask(const int *nbr, int nbr_stride, int K, const int *n_dev,
                                     int n_bound, int *row_order, void *workspace,
                                     size_t workspace_bytes, void *stream) {
-  hipStream_t st = (hipStream_t)stream;
+  return sf_int_row_order(nbr, nbr_stride, K, n_dev, n_bound, row_order, workspace, workspace_bytes, 0,
+                          (hipStream_t)stream);
+}
+
+// the three per-chunk histogram tables inside a row-order workspace (contiguous)
+void sf_int_row_order_hist(void *workspace, int n_bound, uint32_t **hist, size_t *words) {
+  if (n_bound < 1) n_bound = 1;
+  const size_t arr = align_up((size_t)n_bound * 4);
+  const size_t tab = align_up((size_t)sort_blocks(n_bound) * kSortBins * 4);
+  *hist = (uint32_t *)((char *)workspace + 4 * arr);
+  *words = 3 * tab / 4;
+}
+
+int sf_int_row_order(const int *nbr, int nbr_stride, int K, const int *n_dev, int n_bound,
+                     int *row_order, void *workspace, size_t workspace_bytes, int hist_ready,
+                     hipStream_t st) {
   SF_CHECK_ARG(K >= 1 && K <= kMaxK, "kernel volume %d not in [1,%d]", K, kMaxK);
   SF_CHECK_ARG(n_bound >= 0 && nbr_stride >= n_bound, "n_bound=%d nbr_stride=%d", n_bound, nbr_stride);
   if (n_bound == 0) return SF_OK;
@@ -999,9 +1014,11 @@ extern "C" int sf_row_order_by_mask(const int *nbr, int nbr_stride, int K, const
   int *hist0 = (int *)(ws + 4 * arr), *hist1 = (int *)(ws + 4 * arr + tab),
       *hist2 = (int *)(ws + 4 * arr + 2 * tab);
   const PlanView pv = plan_view(row_order, n_bound);
-  hipLaunchKernelGGL(hist_zero_kernel, dim3(nblk < 128 ? nblk : 128), dim3(256), 0, st, n_dev, n_bound,
-                     hist0, tab / 4);
-  SF_CHECK_LAUNCH();
+  if (!hist_ready) {
+    hipLaunchKernelGGL(hist_zero_kernel, dim3(nblk < 128 ? nblk : 128), dim3(256), 0, st, n_dev, n_bound,
+                       hist0, tab / 4);
+    SF_CHECK_LAUNCH();
+  }
   hipLaunchKernelGGL(mask_hist_kernel, dim3(nblk * (kSortChunk / 256)), dim3(256), 0, st, nbr, nbr_stride, K, n_dev,
                      n_bound, keys0, hist0);
   SF_CHECK_LAUNCH();

@@ -25,7 +25,7 @@
 // per frame: 146 MB at the fabric for a 6.4 MB cloud).
 #include <mutex>
 
-#include "sf_common.h"
+#include "front_internal.h"
 
 namespace {
 
@@ -83,7 +83,7 @@ __global__ void vox_fill_kernel(uint2 *__restrict__ kf, long long n_slots, int *
 
 __global__ void vox_insert_kernel(const float *__restrict__ points, int n, int f, VoxParams vp,
                                   uint32_t *__restrict__ kf, uint32_t mask, int *__restrict__ pslot,
-                                  int *__restrict__ misc) {
+                                  int *__restrict__ overflow_dev) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     int c[3];
     if (!point_coor(points + (size_t)i * f, vp, c)) {
@@ -108,7 +108,7 @@ __global__ void vox_insert_kernel(const float *__restrict__ points, int n, int f
     }
     pslot[i] = found;
     if (found < 0) {  // cannot happen with capacity >= n; kept as a guard
-      misc[2] = 1;
+      if (overflow_dev) *overflow_dev = 1;
       continue;
     }
     atomicMin(reinterpret_cast<int *>(kf) + 2 * (size_t)found + 1, i);
@@ -126,8 +126,14 @@ __device__ __forceinline__ bool is_first_point(int i, int n, const int *__restri
 
 __global__ void __launch_bounds__(kThreads)
 vox_count_kernel(int n, const int *__restrict__ pslot, const uint32_t *__restrict__ kf,
-                 int *__restrict__ bsum) {
+                 int *__restrict__ bsum, int *__restrict__ misc,
+                 const int *__restrict__ row_count_dev) {
   __shared__ int smem[17];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {   // read by vox_assign, the next launch
+    misc[0] = SF_INT_MAX;
+    misc[1] = 0;
+    misc[3] = row_count_dev ? *row_count_dev : 0;
+  }
   int base = blockIdx.x * kChunk + threadIdx.x * kItems;
   int c = 0;
 #pragma unroll
@@ -294,6 +300,47 @@ __global__ void vox_reduce_kernel(const float *__restrict__ points, int f, int m
   }
 }
 
+// vox_write + vox_reduce in one launch: a thread owns column k of one voxel (k < max(f, mean
+// stride)), reads the voxel's list once, copies its column of every listed point and sums it in
+// slot order as it goes (the mean adds the same values in the same order as vox_reduce_kernel).
+template <int MP>
+__global__ void vox_write_reduce_kernel(const float *__restrict__ points, int f, int max_points,
+                                        const int *__restrict__ lists, const int *__restrict__ misc,
+                                        float *__restrict__ voxels, int *__restrict__ npv,
+                                        float *__restrict__ mean, int mean_features, int mean_stride) {
+  const int vnum = misc[1], base_row = misc[3];
+  const int cols = (mean && mean_stride > f) ? mean_stride : f;
+  const long long total = (long long)vnum * cols;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int vid = (int)(e / cols), k = (int)(e - (long long)vid * cols);
+    const int *list = lists + (size_t)vid * MP;
+    int j[MP];
+#pragma unroll
+    for (int s = 0; s < MP; ++s) j[s] = list[s];
+    float v[MP];
+#pragma unroll
+    for (int s = 0; s < MP; ++s) v[s] = (k < f && j[s] != SF_INT_MAX) ? points[(size_t)j[s] * f + k] : 0.0f;
+    int cnt = 0;
+    float sum = 0.0f;
+#pragma unroll
+    for (int s = 0; s < MP; ++s) {
+      if (j[s] != SF_INT_MAX) {   // lists ascend; INT_MAX marks empty
+        ++cnt;
+        sum += v[s];
+      }
+    }
+    const size_t row = (size_t)(base_row + vid);
+    if (k < f) {
+      float *dst = voxels + row * MP * f + k;
+#pragma unroll
+      for (int s = 0; s < MP; ++s) dst[(size_t)s * f] = v[s];
+    }
+    if (k == 0 && npv) npv[row] = cnt;
+    if (mean && k < mean_stride) mean[row * mean_stride + k] = k < mean_features ? sum / (float)cnt : 0.0f;
+  }
+}
+
 // Standalone HardSimpleVFE (voxel_encoder.py:42-44) on an already materialised voxel tensor.
 __global__ void voxel_mean_kernel(const float *__restrict__ voxels, const int *__restrict__ npv,
                                   const int *m_dev, int m_bound, int max_points, int f, int nf,
@@ -401,7 +448,8 @@ int hard_voxelize_impl(const float *points, int n, int f, const float voxel_size
                        int *coors, int coors_stride, int batch_idx, int *num_points_per_voxel,
                        float *mean, int mean_features, int mean_stride, int *row_count_dev,
                        int rows_capacity, int *overflow_dev, int *voxel_num_host, void *workspace,
-                       size_t workspace_bytes, hipStream_t st) {
+                       size_t workspace_bytes, hipStream_t st, const SfVoxFuse *fuse = nullptr) {
+
   SF_CHECK_ARG(n >= 0 && f >= 3, "bad shape n=%d f=%d (need f >= 3)", n, f);
   SF_CHECK_ARG(max_points >= 1, "max_points=%d: the hard path needs max_points >= 1 "
                "(use sf_dynamic_voxelize for -1)", max_points);
@@ -422,15 +470,18 @@ int hard_voxelize_impl(const float *points, int n, int f, const float voxel_size
   }
   SF_CHECK_ARG(n == 0 || points, "points is NULL");
 
-  hipLaunchKernelGGL(vox_fill_kernel, dim3(sf_grid(w.cap / 2, kThreads)), dim3(kThreads), 0, st,
-                     reinterpret_cast<uint2 *>(w.kf), w.cap, w.misc, (const int *)row_count_dev);
-  SF_CHECK_LAUNCH();
+  if (!(fuse && fuse->tables_ready && n > 0)) {
+    hipLaunchKernelGGL(vox_fill_kernel, dim3(sf_grid(w.cap / 2, kThreads)), dim3(kThreads), 0, st,
+                       reinterpret_cast<uint2 *>(w.kf), w.cap, w.misc, (const int *)row_count_dev);
+    SF_CHECK_LAUNCH();
+  }
   if (n > 0) {
     hipLaunchKernelGGL(vox_insert_kernel, dim3(sf_grid(n, kThreads)), dim3(kThreads), 0, st, points,
-                       n, f, vp, w.kf, (uint32_t)(w.cap - 1), w.pslot, w.misc);
+                       n, f, vp, w.kf, (uint32_t)(w.cap - 1), w.pslot, overflow_dev);
     SF_CHECK_LAUNCH();
     hipLaunchKernelGGL(vox_count_kernel, dim3(w.nblk), dim3(kThreads), 0, st, n,
-                       (const int *)w.pslot, (const uint32_t *)w.kf, w.bsum);
+                       (const int *)w.pslot, (const uint32_t *)w.kf, w.bsum, w.misc,
+                       (const int *)row_count_dev);
     SF_CHECK_LAUNCH();
     hipLaunchKernelGGL(vox_assign_kernel, dim3(w.nblk), dim3(kThreads), 0, st, n, max_points,
                        max_voxels, vp, (const int *)w.pslot, (const uint32_t *)w.kf,
@@ -446,13 +497,22 @@ int hard_voxelize_impl(const float *points, int n, int f, const float voxel_size
                        (const int *)w.pslot, (const int *)w.slot_vid, (const int *)w.misc, w.lists);
     SF_CHECK_LAUNCH();
     long long bound_v = (max_voxels >= 0 && max_voxels < n) ? max_voxels : n;
-    if (voxels) {
+    const bool fused_wr = voxels && (num_points_per_voxel || mean) && (max_points == 10 || max_points == 5);
+    if (fused_wr) {
+      const long long cols = (mean && mean_stride > f) ? mean_stride : f;
+      auto kern = max_points == 10 ? vox_write_reduce_kernel<10> : vox_write_reduce_kernel<5>;
+      hipLaunchKernelGGL(kern, dim3(sf_grid(bound_v * cols, kThreads)), dim3(kThreads), 0, st, points, f,
+                         max_points, (const int *)w.lists, (const int *)w.misc, voxels,
+                         num_points_per_voxel, mean, mean_features, mean_stride);
+      SF_CHECK_LAUNCH();
+    }
+    if (voxels && !fused_wr) {
       hipLaunchKernelGGL(vox_write_kernel, dim3(sf_grid(bound_v * max_points * f, kThreads)),
                          dim3(kThreads), 0, st, points, f, max_points, (const int *)w.lists,
                          (const int *)w.misc, voxels);
       SF_CHECK_LAUNCH();
     }
-    if (num_points_per_voxel || mean) {
+    if ((num_points_per_voxel || mean) && !fused_wr) {
       long long cols = mean ? mean_stride : 1;
       hipLaunchKernelGGL(vox_reduce_kernel, dim3(sf_grid(bound_v * cols, kThreads)), dim3(kThreads),
                          0, st, points, f, max_points, (const int *)w.lists, (const int *)w.misc,
@@ -497,6 +557,24 @@ int static_scratch(void **ptr) {
 }
 
 }  // namespace
+
+int sf_int_hard_voxelize(const float *points, int n, int f, const float voxel_size[3],
+                         const float coors_range[6], int max_points, int max_voxels, float *voxels,
+                         int *coors, int coors_stride, int batch_idx, int *num_points_per_voxel,
+                         float *mean, int mean_features, int mean_stride, int *row_count_dev,
+                         int rows_capacity, int *overflow_dev, int *voxel_num_host, void *workspace,
+                         size_t workspace_bytes, hipStream_t st, const SfVoxFuse *fuse) {
+  return hard_voxelize_impl(points, n, f, voxel_size, coors_range, max_points, max_voxels, voxels,
+                            coors, coors_stride, batch_idx, num_points_per_voxel, mean,
+                            mean_features, mean_stride, row_count_dev, rows_capacity, overflow_dev,
+                            voxel_num_host, workspace, workspace_bytes, st, fuse);
+}
+
+void sf_int_vox_table(void *workspace, int n, int max_points, uint32_t **table, size_t *words) {
+  VoxWorkspace w = carve(workspace, n, max_points);
+  *table = w.kf;
+  *words = (size_t)w.cap * 2;
+}
 
 extern "C" int sf_hard_voxelize(const float *points, int n, int f, const float voxel_size[3],
                                 const float coors_range[6], int max_points, int max_voxels,

@@ -95,7 +95,7 @@ class LidarBackbone:
     def __init__(self, voxel_layer_cfg, encoder, device, max_points, batch_size=1,
                  materialize_voxels=True, training=False, overlap=True, dtype='f32',
                  voxel_encoder=None, bev_backbone=None, neck=None,
-                 heights_out_size_factor=None, strided_growth=None):
+                 heights_out_size_factor=None, strided_growth=None, fused_front=True):
         """dtype 'f32': every layer on the exact-fp32 kernels.  'bf16' (BASELINE configs[2]): the
         first layer stays fp32 (raw metric coordinates need more than 8 significant bits), its
         output is cast to bf16, every later layer runs on the bf16 matrix cores with fp32
@@ -147,6 +147,11 @@ class LidarBackbone:
         self.mv = int(mv[0] if training else mv[1])
         self.materialize = materialize_voxels
         self.overlap = bool(overlap)      # coordinate phase on a second stream
+        # fused_front: wherever the coordinate phase runs on ONE stream (capture_split, overlap=False)
+        # it is enqueued by one sf_lidar_front call (fewer launches, same buffers) instead of the
+        # stand-alone entry points
+        self.fused_front = bool(fused_front)
+        self._front_desc = None
         self.side_stream = torch.cuda.Stream(device=self.dev) if self.overlap else None
         self._last_segment_done = None   # capture_split: event at the end of this object's last batch
         self.enc = encoder
@@ -239,8 +244,12 @@ class LidarBackbone:
         self.rb_ws = torch.empty(max(ws, 256), dtype=torch.uint8, device=dev)
         self.rb_ws_bytes = max(ws, 256)
         vws = L.sf_hard_voxelize_workspace(self.max_points_in, self.mp)
-        self.vox_ws = torch.empty(vws, dtype=torch.uint8, device=dev)
+        vws = (vws + 255) & ~255
+        self.vox_ws = torch.empty(vws * self.B, dtype=torch.uint8, device=dev)   # a slice per sample
         self.vox_ws_bytes = vws
+        for rb in self.rulebooks:   # first-touch words of a strided rulebook (sf_lidar_front)
+            if not rb['subm']:
+                rb['first'] = i32(self.sets[rb['dst']]['cap'])
         self.cin_pad = L.sf_conv_padded_cin(self.in_channels)
         self.mean = f32(n0, self.cin_pad)                  # fused VFE output, zero padded columns
         self.voxels = None                                  # allocated once F is known
@@ -300,6 +309,8 @@ class LidarBackbone:
             yield from (s['indices'], s['keys'], s['vals'])
         for rb in self.rulebooks:
             yield rb['nbr']
+            if 'first' in rb:
+                yield rb['first']
         for bufs in self.fbufs.values():
             yield from bufs
         yield from (self.rb_ws, self.vox_ws, self.mean, self.num_points, self.bev)
@@ -318,6 +329,11 @@ class LidarBackbone:
         input instead of the fused per-voxel mean (configs whose voxel encoder is a learned VFE,
         e.g. the Waymo config's 64-channel HardVFE, which is not part of this path)."""
         dev = self.dev
+        if self.fused_front and not (self.overlap and len(self.rulebooks) > 1):
+            self._front_fused(points_list, voxel_features)
+            self._feature_input(voxel_features)
+            self._features(0, len(self.layers), {})
+            return self._dense_and_after()
         self._front(points_list, voxel_features)
         # ---- coordinate phase: on its own stream, forked after the voxelizer ---------------
         # The hash / neighbour-table kernels are latency bound and need no LDS: they run in the
@@ -380,6 +396,65 @@ class LidarBackbone:
                             self.B, s0['keys'].data_ptr(), s0['vals'].data_ptr(), s0['cap'], ovf,
                             st))
         self._rulebook(0, st)
+
+    def _front_fused(self, points_list, voxel_features):
+        """The whole coordinate phase (voxelizer, hashes, every rulebook, plans) by ONE call of
+        sf_lidar_front on the current stream."""
+        import ctypes as C
+        L, dev = self.L, self.dev
+        if len(points_list) != self.B:
+            raise RuntimeError(f'expected {self.B} samples, got {len(points_list)}')
+        if self.F is None:
+            self.F = int(points_list[0].shape[1])
+            if self.materialize:
+                self.voxels = torch.empty((self.B * self.mv, self.mp, self.F), dtype=torch.float32,
+                                          device=dev)
+        if voxel_features is None and self.vfe is None and self.in_channels > self.F:
+            raise RuntimeError(f'encoder wants {self.in_channels} input channels but points have '
+                               f'{self.F} features: pass voxel_features')
+        for pts in points_list:
+            if pts.shape[0] > self.max_points_in or pts.shape[1] != self.F:
+                raise RuntimeError('point cloud larger than max_points or feature count changed')
+            _lib.require(pts, torch.float32, 'points')
+        if self._front_desc is None:
+            sets = (_lib.SfCoordSet * len(self.sets))()
+            for cs, s in zip(sets, self.sets):
+                cs.shape[:] = [int(v) for v in s['shape']]
+                cs.bound, cs.capacity = s['bound'], s['cap']
+                cs.indices, cs.keys, cs.vals = s['indices'].data_ptr(), s['keys'].data_ptr(), s['vals'].data_ptr()
+            rbs = (_lib.SfRulebook * len(self.rulebooks))()
+            ws = 0
+            for cr, rb in zip(rbs, self.rulebooks):
+                cr.src, cr.dst, cr.subm = rb['src'], rb['dst'], 1 if rb['subm'] else 0
+                cr.ksize[:], cr.stride[:], cr.padding[:] = rb['ks'], rb['st'], rb['pd']
+                cr.nbr, cr.nbr_stride = rb['nbr'].data_ptr(), rb['stride']
+                if 'order' in rb:
+                    cr.plan, cr.plan_ws = rb['order'].data_ptr(), rb['order_ws'].data_ptr()
+                    cr.plan_ws_bytes = rb['order_ws_bytes']
+                if 'first' in rb:
+                    cr.first = rb['first'].data_ptr()
+            d = _lib.SfFrontDesc()
+            d.batch = self.B
+            d.points = (C.c_void_p * self.B)()
+            d.num_points = (C.c_int * self.B)()
+            d.num_features = self.F
+            d.voxel_size[:] = [float(v) for v in self.voxel_size]
+            d.coors_range[:] = [float(v) for v in self.pc_range]
+            d.max_points, d.max_voxels = self.mp, self.mv
+            d.voxels = self.voxels.data_ptr() if self.materialize else None
+            d.num_points_per_voxel = self.num_points.data_ptr()
+            d.mean = self.mean.data_ptr() if self.vfe is None else None
+            d.mean_features, d.mean_stride = min(self.in_channels, self.F), self.cin_pad
+            d.vox_workspace, d.vox_workspace_bytes = self.vox_ws.data_ptr(), self.vox_ws_bytes
+            d.n_sets, d.sets, d.counts_dev = len(self.sets), sets, self.counts.data_ptr()
+            d.n_rulebooks, d.rulebooks = len(self.rulebooks), rbs
+            d.rb_workspace, d.rb_workspace_bytes = self.rb_ws.data_ptr(), self.rb_ws_bytes
+            self._front_desc = (d, sets, rbs, d.points, d.num_points)
+        d = self._front_desc[0]
+        pts_arr = (C.c_void_p * self.B)(*[_lib.ptr(p) for p in points_list])
+        n_arr = (C.c_int * self.B)(*[int(p.shape[0]) for p in points_list])
+        d.points, d.num_points = pts_arr, n_arr
+        _lib.check(L.sf_lidar_front(C.byref(d), _lib.stream(dev)))
 
     def _rulebook(self, ri, ss):
         """Rulebook `ri` (and its mask order, where a layer uses one) on the raw stream `ss`."""
@@ -611,6 +686,9 @@ class LidarBackbone:
         torch.cuda.synchronize(dev)
 
         def front():
+            if self.fused_front:
+                self._front_fused(points_list, voxel_features)
+                return
             self._front(points_list, voxel_features)
             ss = _lib.stream(dev)
             for ri in range(1, len(self.rulebooks)):
