@@ -313,6 +313,9 @@ def main():
                     help='submit the frames through pipeline.FramePipeline (graphs captured once per '
                          'object, every frame COPIED into a static point buffer first: what a caller '
                          'with a stream of new frames runs) instead of graphs bound to the resident frames')
+    ap.add_argument('--cut', type=int, default=None,
+                    help='split pipeline: first layer of the wide-layer segment (default: the first '
+                         'layer with >= 64 input channels)')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-overlap', action='store_true',
                     help='coordinate phase on the main stream instead of a forked one')
@@ -389,7 +392,8 @@ def main():
                     fns = [(lambda f=f, lane=lane: lane.enqueue(f, vf)) for f in frames]
                 elif split:
                     light = (light0, light1)[li % 2]
-                    sfs = [lane.capture_split(f, [light, narrow_st or light, wide_st], voxel_features=vf)
+                    sfs = [lane.capture_split(f, [light, narrow_st or light, wide_st], cut=args.cut,
+                                              voxel_features=vf)
                            for f in frames]
                     split_frames.append(sfs)
                     fns = [(lambda sf=sf: sf.replay(timed=wide_events)) for sf in sfs]

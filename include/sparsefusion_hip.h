@@ -408,6 +408,18 @@ SF_API int sf_sparse_conv_f32_ordered(const float *features_in, int n_in_bound, 
 SF_API int sf_dense_bev(const float *features, const int *indices, const int *n_dev, int n_bound,
                         int channels, int batch, int D, int H, int W, float *out, void *stream);
 
+/* sf_dense_bev in two calls, for a pipeline that knows the output coordinates long before the
+ * features (the rulebooks of a frame are built while the previous frame still convolves):
+ * sf_dense_bev_mark writes the cell -> row map into the c = 0 planes of `out` (zero fill + one
+ * mark per row; needs `indices` only), sf_dense_bev_write then writes every channel plane from
+ * `features` (and overwrites the map with the real channel 0 last).  mark, write in this order,
+ * with the same (n_dev, n_bound, shape, out), equal sf_dense_bev; `out` must not be touched in
+ * between.  Same reference lines as sf_dense_bev. */
+SF_API int sf_dense_bev_mark(const int *indices, const int *n_dev, int n_bound, int channels,
+                             int batch, int D, int H, int W, float *out, void *stream);
+SF_API int sf_dense_bev_write(const float *features, const int *n_dev, int n_bound, int channels,
+                              int batch, int D, int H, int W, float *out, void *stream);
+
 /* Zero-pad feature columns: src (n, c_src) -> dst (n, c_dst), c_dst >= c_src. */
 SF_API int sf_pad_channels_f32(const float *src, int c_src, float *dst, int c_dst,
                                const int *n_dev, int n_bound, void *stream);

@@ -88,6 +88,8 @@ SIGNATURES = {
     'sf_sparse_conv_bf16': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp,
                                  _i, _vp, _i, _vp]),
     'sf_dense_bev': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    'sf_dense_bev_mark': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    'sf_dense_bev_write': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'sf_conv2d_packed_bytes': (_sz, [_i, _i, _i, _i]),
     'sf_conv2d_pack_filters_f32': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     'sf_conv2d_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,

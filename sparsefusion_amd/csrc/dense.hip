@@ -86,16 +86,28 @@ dense_write_kernel(const float *__restrict__ feat, const int *n_dev, int n_bound
 
 }  // namespace
 
-extern "C" int sf_dense_bev(const float *features, const int *indices, const int *n_dev,
-                            int n_bound, int channels, int batch, int D, int H, int W, float *out,
-                            void *stream) {
-  hipStream_t st = (hipStream_t)stream;
+namespace {
+
+int dense_check(const void *features, const void *indices, int n_bound, int channels, int batch, int D,
+                int H, int W, const void *out, bool need_feat, bool need_idx) {
   SF_CHECK_ARG(channels >= 1 && batch >= 1 && D >= 1 && H >= 1 && W >= 1 && n_bound >= 0,
                "bad dense shape");
   SF_CHECK_ARG(out, "out is NULL");
-  SF_CHECK_ARG(n_bound == 0 || (features && indices), "features / indices is NULL");
+  SF_CHECK_ARG(n_bound == 0 || ((!need_feat || features) && (!need_idx || indices)),
+               "features / indices is NULL");
+  return SF_OK;
+}
+
+}  // namespace
+
+// first half of sf_dense_bev: the cell -> row map in the c = 0 planes of `out` (needs the output
+// coordinates only, so a pipeline can run it beside the convolutions)
+extern "C" int sf_dense_bev_mark(const int *indices, const int *n_dev, int n_bound, int channels,
+                                 int batch, int D, int H, int W, float *out, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  int rc = dense_check(nullptr, indices, n_bound, channels, batch, D, H, W, out, false, true);
+  if (rc != SF_OK) return rc;
   const size_t plane = (size_t)H * W;
-  // the c = 0 planes: the temporary cell -> row map
   hipLaunchKernelGGL(dense_zero_kernel, dim3(sf_grid((long long)batch * D * plane, 256)), dim3(256), 0,
                      st, out, channels, batch, D, plane);
   SF_CHECK_LAUNCH();
@@ -104,10 +116,29 @@ extern "C" int sf_dense_bev(const float *features, const int *indices, const int
                        n_dev, n_bound, channels, batch, D, H, W, out);
     SF_CHECK_LAUNCH();
   }
+  return SF_OK;
+}
+
+// second half: every channel plane written from the rows the map names
+extern "C" int sf_dense_bev_write(const float *features, const int *n_dev, int n_bound, int channels,
+                                  int batch, int D, int H, int W, float *out, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  int rc = dense_check(features, nullptr, n_bound, channels, batch, D, H, W, out, true, false);
+  if (rc != SF_OK) return rc;
   const long long lines = (long long)batch * D * H * ((W + 63) / 64);
   const int grid = (int)(lines < 8192 ? lines : 8192);
   hipLaunchKernelGGL((dense_write_kernel<128>), dim3(grid), dim3(256), 0, st, features, n_dev, n_bound,
                      channels, batch, D, H, W, out);
   SF_CHECK_LAUNCH();
   return SF_OK;
+}
+
+extern "C" int sf_dense_bev(const float *features, const int *indices, const int *n_dev,
+                            int n_bound, int channels, int batch, int D, int H, int W, float *out,
+                            void *stream) {
+  int rc = dense_check(features, indices, n_bound, channels, batch, D, H, W, out, true, true);
+  if (rc != SF_OK) return rc;
+  rc = sf_dense_bev_mark(indices, n_dev, n_bound, channels, batch, D, H, W, out, stream);
+  if (rc != SF_OK) return rc;
+  return sf_dense_bev_write(features, n_dev, n_bound, channels, batch, D, H, W, out, stream);
 }

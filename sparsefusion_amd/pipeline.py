@@ -329,6 +329,7 @@ class LidarBackbone:
         input instead of the fused per-voxel mean (configs whose voxel encoder is a learned VFE,
         e.g. the Waymo config's 64-channel HardVFE, which is not part of this path)."""
         dev = self.dev
+        self._dense_marked = False
         if self.fused_front and not (self.overlap and len(self.rulebooks) > 1):
             self._front_fused(points_list, voxel_features)
             self._feature_input(voxel_features)
@@ -585,8 +586,12 @@ class LidarBackbone:
         x = self._fstate[0]
         o = self.sets[self.out_set]
         D, H, W = o['shape']
-        chk(L.sf_dense_bev(x.data_ptr(), o['indices'].data_ptr(), c0 + 4 * self.out_set, o['bound'],
-                           self.out_channels, self.B, D, H, W, self.bev.data_ptr(), st))
+        if getattr(self, '_dense_marked', False):     # the front of this capture built the map
+            chk(L.sf_dense_bev_write(x.data_ptr(), c0 + 4 * self.out_set, o['bound'],
+                                     self.out_channels, self.B, D, H, W, self.bev.data_ptr(), st))
+        else:
+            chk(L.sf_dense_bev(x.data_ptr(), o['indices'].data_ptr(), c0 + 4 * self.out_set, o['bound'],
+                               self.out_channels, self.B, D, H, W, self.bev.data_ptr(), st))
         if self.bev_backbone is None:
             return self.bev
         feats = self.bev_backbone(self.bev)
@@ -684,10 +689,19 @@ class LidarBackbone:
         torch.cuda.synchronize(dev)      # earlier batches of this object may still be in flight
         self.enqueue(points_list, voxel_features)
         torch.cuda.synchronize(dev)
+        self._dense_marked = False
 
         def front():
             if self.fused_front:
                 self._front_fused(points_list, voxel_features)
+                # the cell -> row map of the dense writer needs the output coordinates only: built
+                # here, beside the wide layers of the frame before, not behind those of this one
+                o = self.sets[self.out_set]
+                D, H, W = o['shape']
+                _lib.check(self.L.sf_dense_bev_mark(
+                    o['indices'].data_ptr(), self.counts.data_ptr() + 4 * self.out_set, o['bound'],
+                    self.out_channels, self.B, D, H, W, self.bev.data_ptr(), _lib.stream(dev)))
+                self._dense_marked = True
                 return
             self._front(points_list, voxel_features)
             ss = _lib.stream(dev)
