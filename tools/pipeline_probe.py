@@ -31,6 +31,9 @@ def main():
                     help='create the wide-layer stream with this priority (-1 = high) instead of '
                          'taking it from the probed pool')
     ap.add_argument('--quiet', action='store_true', help='totals only')
+    ap.add_argument('--light-cus', type=int, default=0,
+                    help='create the two light streams with a CU mask of this many CUs (hipExtStreamCreateWithCUMask)')
+    ap.add_argument('--wide-rest', action='store_true', help='with --light-cus: the wide stream on the other CUs only')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     torch.cuda.set_device(dev)
@@ -38,7 +41,23 @@ def main():
     max_pts = max(p.shape[0] for p in host)
     cfg, ecfg, sd, enc, bb = bench.build_backbone('nusc', dev, 1, max_pts)
     lanes = [bb] + [LidarBackbone(cfg['pts_voxel_layer'], enc, dev, max_pts) for _ in range(args.lanes - 1)]
-    if args.wide_priority is None:
+    if args.light_cus:
+        import ctypes
+        hip = ctypes.CDLL('libamdhip64.so')
+        words = 8
+
+        def masked(bits):
+            m = (ctypes.c_uint32 * words)(*[(bits >> (32 * i)) & 0xFFFFFFFF for i in range(words)])
+            st = ctypes.c_void_p()
+            rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), words, m)
+            assert rc == 0, rc
+            return torch.cuda.ExternalStream(st.value, device=dev)
+        lo = (1 << args.light_cus) - 1
+        hi = ((1 << 256) - 1) ^ lo
+        l0, l1, wide = masked(lo), masked(lo), masked(hi if args.wide_rest else (1 << 256) - 1)
+        nq = 3
+        print('CU masks: light', args.light_cus, 'CUs, wide', 'the rest' if args.wide_rest else 'all')
+    elif args.wide_priority is None:
         (l0, l1, wide), nq = concurrent_streams(dev, 3)
     else:
         (l0, l1), nq = concurrent_streams(dev, 2)
