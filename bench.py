@@ -316,6 +316,9 @@ def main():
     ap.add_argument('--cut', type=int, default=None,
                     help='split pipeline: first layer of the wide-layer segment (default: the first '
                          'layer with >= 64 input channels)')
+    ap.add_argument('--ordered', default=None,
+                    help="A/B runs: fp32 layer shapes on the mask-ordered kernel ('all', 'none' or "
+                         "a list like 32x32,64x64); default: spconv.ORDERED_SHAPES")
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-overlap', action='store_true',
                     help='coordinate phase on the main stream instead of a forked one')
@@ -323,6 +326,9 @@ def main():
     ap.add_argument('--cpu-passes', type=int, default=5, help='timed passes of the CPU baseline')
     ap.add_argument('--detail', default='', help='write per-layer timing/roofline JSON here')
     args = ap.parse_args()
+    if args.ordered is not None:
+        from sparsefusion_amd import spconv as _spconv
+        _spconv.ORDERED_SHAPES = args.ordered
 
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))

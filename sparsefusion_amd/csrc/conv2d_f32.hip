@@ -359,24 +359,15 @@ int dispatch_th(int th, int ng, const float *in, const float *wp, const float *s
     if (th == 6) return launch<KS, S, 6, 2>(in, wp, scale, shift, out, a, st);
     return launch<KS, S, 4, 2>(in, wp, scale, shift, out, a, st);
   }
-  switch (th) {
-    case 2: return launch<KS, S, 2, 4>(in, wp, scale, shift, out, a, st);
-    case 3: return launch<KS, S, 3, 4>(in, wp, scale, shift, out, a, st);
-    case 4: return launch<KS, S, 4, 4>(in, wp, scale, shift, out, a, st);
-    default: return launch<KS, S, 6, 4>(in, wp, scale, shift, out, a, st);
-  }
+  if (th == 6) return launch<KS, S, 6, 4>(in, wp, scale, shift, out, a, st);
+  return launch<KS, S, 4, 4>(in, wp, scale, shift, out, a, st);
 }
 
 // Channels per workgroup: 64, or 32 where the 64-channel grid is about two workgroups per CU (one
 // 180x180 map at batch 1: 540 workgroups on 256 CUs; 1080 half-width ones measured 4 % faster:
 // 131 vs 137 us for 128->128).  Smaller grids (a 90x90 map: 276) and the 1x1 / stride-2 layers
-// measured SLOWER with 32 channels (169 vs 161 us, 92 vs 80 us): they keep 64.  SF_CONV2D_NG=2|4
-// overrides.
+// measured SLOWER with 32 channels (169 vs 161 us, 92 vs 80 us): they keep 64.
 int pick_groups(const Conv2dArgs &a, int th) {
-  if (const char *e = getenv("SF_CONV2D_NG")) {
-    const int v = atoi(e);
-    if (v == 2 || v == 4) return v;
-  }
   const long long wgs = (long long)a.B * sf_div_up(a.Ho, th) * a.nxt * sf_div_up(a.cout_packed, 64);
   return (wgs >= 400 && wgs < 4 * 256 && a.cout_packed % 32 == 0) ? 2 : 4;
 }
@@ -387,10 +378,6 @@ int pick_groups(const Conv2dArgs &a, int th) {
 // they save a whole round of workgroups on the 256 CUs (a 90x90 map at batch 1: 180 workgroups
 // instead of 276).
 int pick_rows(const Conv2dArgs &a) {
-  if (const char *e = getenv("SF_CONV2D_TH")) {
-    const int v = atoi(e);
-    if (v == 2 || v == 3 || v == 4 || v == 6) return v;
-  }
   auto cost = [&](int th) {
     const long long wgs = (long long)a.B * sf_div_up(a.Ho, th) * a.nxt * a.nct;
     return ((wgs + 255) / 256) * th;

@@ -444,18 +444,11 @@ int launch_tile(const ConvArgs &a) {
     sf_set_error("bf16 tile shape tm=%d cg=%d does not fit cout=%d", TM, CG, COUT);
     return SF_ERR_BAD_ARG;
   } else {
-    // grid = workgroups resident at once (CUs x occupancy), a multiple of 8, never more than
-    // the bound needs
-    static SfSlotCache cache = {};
-    int slots = sf_resident_slots(cache, conv_bf16_tile_kernel<CIN, COUT, TM, CG, 4, 2>, 256, 0);
-    SF_CHECK_ARG(slots > 0, "cannot query the device for the resident workgroups");
-    slots &= ~7;
-    if (slots < 8) slots = 8;
-    static int balance = -1;
-    if (balance < 0) balance = getenv("SF_BF16_BALANCE") ? atoi(getenv("SF_BF16_BALANCE")) & 1 : 0;
-    int grid = (sf_div_up(a.n_out_bound, balance ? 16 : TM) + 7) & ~7;
-    const int cap = balance ? slots : 8192;
-    if (grid > cap) grid = cap;
+    // plain tiling: one tile per workgroup, the grid a multiple of 8 (the balanced hand-out over
+    // the resident workgroups measured no faster for these shapes)
+    const int balance = 0;
+    int grid = (sf_div_up(a.n_out_bound, TM) + 7) & ~7;
+    if (grid > 8192) grid = 8192;
     sf_note_kernel("conv_bf16_tile_kernel<%d, %d, %d, %d, 4, 2>", CIN, COUT, TM, CG);
     hipLaunchKernelGGL((conv_bf16_tile_kernel<CIN, COUT, TM, CG, 4, 2>), dim3(grid), dim3(256), 0,
                        a.st, a.feat, a.feat_bytes, a.nbr, a.nbr_stride, a.K, a.k_first, a.wpk,
@@ -466,49 +459,16 @@ int launch_tile(const ConvArgs &a) {
   }
 }
 
-// Experiment hooks (read once): SF_BF16_DIRECT="mb,d1" (0,0 = never use the direct kernel),
-// SF_BF16_TILE="tm,cg".
-void env_pair(const char *name, int &x, int &y) {
-  x = y = -1;
-  const char *e = getenv(name);
-  if (e && sscanf(e, "%d,%d", &x, &y) != 2) x = y = -1;
-}
-
+// Measured choices (tools/sweep_bf16.sh at the time): the direct kernel (2 row blocks per wave,
+// look-ahead 2) for the 27-offset layers up to 32 input channels, 64-row tiles with the widest
+// column-group split elsewhere.
 template <int CIN, int COUT>
 int launch_cfg(const ConvArgs &a) {
-  static int dmb = -2, dd1, ttm, tcg;
-  if (dmb == -2) {
-    env_pair("SF_BF16_TILE", ttm, tcg);
-    env_pair("SF_BF16_DIRECT", dmb, dd1);
-  }
   if constexpr (CIN <= 32 && COUT <= 64) {
-    if (a.K == 27 && dmb != 0) {
-      switch (dmb * 10 + dd1) {
-        case 11: return launch_direct<CIN, COUT, 1, 1>(a);
-        case 12: return launch_direct<CIN, COUT, 1, 2>(a);
-        case 13: return launch_direct<CIN, COUT, 1, 3>(a);
-        case 21: return launch_direct<CIN, COUT, 2, 1>(a);
-        case 22: return launch_direct<CIN, COUT, 2, 2>(a);
-        case 41: return launch_direct<CIN, COUT, 4, 1>(a);
-      }
-      return launch_direct<CIN, COUT, 2, 2>(a);
-    }
+    if (a.K == 27) return launch_direct<CIN, COUT, 2, 2>(a);
   }
   constexpr int NB = COUT / 16;
   constexpr int CGMAX = NB >= 4 ? 4 : NB;
-  constexpr int CGHALF = CGMAX >= 2 ? CGMAX / 2 : 1;
-  if constexpr (CIN >= 64) {  // tuning variants only where the tile kernel is the hot one
-    if (ttm > 0) {
-      if (ttm == 64 && tcg == CGMAX) return launch_tile<CIN, COUT, 64, CGMAX>(a);
-      if (ttm == 80 && tcg == CGMAX) return launch_tile<CIN, COUT, 80, CGMAX>(a);
-      if (ttm == 96 && tcg == CGMAX) return launch_tile<CIN, COUT, 96, CGMAX>(a);
-      if (ttm == 128 && tcg == CGMAX) return launch_tile<CIN, COUT, 128, CGMAX>(a);
-      if (ttm == 64 && tcg == CGHALF) return launch_tile<CIN, COUT, 64, CGHALF>(a);
-      if (ttm == 96 && tcg == CGHALF) return launch_tile<CIN, COUT, 96, CGHALF>(a);
-      if (ttm == 128 && tcg == CGHALF) return launch_tile<CIN, COUT, 128, CGHALF>(a);
-    }
-    return launch_tile<CIN, COUT, 64, CGMAX>(a);
-  }
   return launch_tile<CIN, COUT, 64, CGMAX>(a);
 }
 

@@ -913,19 +913,11 @@ const int *g_row_order = nullptr;            // experiment hook, see sf_debug_co
 
 using ConvArgs = SfConvArgs;
 
-// Balanced tiling pays where a layer has only ~2 tiles per resident workgroup (the 128-channel
-// stage: 33k rows / 64 = 520 tiles on 256 CUs); SF_CONV_BALANCE=0/1 overrides for experiments.
-int env_balance(int dflt) {
-  static int v = -2;
-  if (v == -2) {
-    const char *e = getenv("SF_CONV_BALANCE");
-    v = e ? atoi(e) : -1;
-  }
-  return v < 0 ? dflt : (v & 1);
-}
-
+// Balanced tiling (32-row units handed out over the resident workgroups) pays where a layer has
+// only ~2 tiles per resident workgroup (the 128-channel stage: 33k rows / 64 = 520 tiles on 256
+// CUs); each call site passes the measured choice for its shape.
 template <int CIN, int COUT, int TM, int AM, int WAVES, int ABUF>
-int launch(const ConvArgs &a, int balance_default) {
+int launch(const ConvArgs &a, int balance) {
   constexpr int TMP = (TM + 15) & ~15;
   constexpr size_t lds = (size_t)(TM + 1) * (COUT + 4) * 4 + (size_t)ABUF * AM * CIN * 4 +
                          (size_t)kMaxK * TMP * 5 + (size_t)kMaxK * (((TM + AM - 1) / AM) + 1) * 4 +
@@ -936,7 +928,6 @@ int launch(const ConvArgs &a, int balance_default) {
   const int slots = sf_resident_slots(cache, sparse_conv_f32_kernel<CIN, COUT, TM, AM, WAVES, ABUF>,
                                       WAVES * 64, 0, lds);
   SF_CHECK_ARG(slots > 0, "cannot query the device for the resident workgroups");
-  const int balance = env_balance(balance_default);
   int tiles = sf_div_up(a.n_out_bound, balance ? 32 : TM);
   int cap = balance ? slots : 4096;
   int grid = tiles < cap ? tiles : cap;
@@ -950,7 +941,7 @@ int launch(const ConvArgs &a, int balance_default) {
 }
 
 template <int CIN, int COUT, int TM, int AM, int WAVES, int MINW = 1>
-int launch_wide(const ConvArgs &a, int balance_default) {
+int launch_wide(const ConvArgs &a, int balance) {
   constexpr bool ok = (COUT / 16) % WAVES == 0 && (AM * (CIN / 4)) % (WAVES * 64) == 0 && CIN >= 32;
   if constexpr (!ok) {  // shape outside the wide kernel: the general kernel at its usual tile
     return launch<CIN, COUT, 80, 64, 4, 1>(a, 1);
@@ -963,8 +954,7 @@ int launch_wide(const ConvArgs &a, int balance_default) {
     const int slots = sf_resident_slots(cache, sparse_conv_f32_wide_kernel<CIN, COUT, TM, AM, WAVES, MINW>,
                                         WAVES * 64, 0, lds);
     SF_CHECK_ARG(slots > 0, "cannot query the device for the resident workgroups");
-    const int balance = env_balance(balance_default);
-    int tiles = sf_div_up(a.n_out_bound, balance ? 32 : TM);
+      int tiles = sf_div_up(a.n_out_bound, balance ? 32 : TM);
     int cap = balance ? slots : 4096;
     int grid = tiles < cap ? tiles : cap;
     sf_note_kernel("sparse_conv_f32_wide_kernel<%d, %d, %d, %d, %d, %d>", CIN, COUT, TM, AM, WAVES, MINW);
@@ -989,127 +979,27 @@ int launch_direct(const ConvArgs &a) {
   return SF_OK;
 }
 
-// Experiment hook: SF_CONV_CFG="tm,am,waves,abuf" overrides the per-shape default (read once).
-long env_cfg() {
-  static long cfg = -2;
-  if (cfg == -2) {
-    cfg = -1;
-    const char *e = getenv("SF_CONV_CFG");
-    int tm, am, w, ab;
-    if (e && sscanf(e, "%d,%d,%d,%d", &tm, &am, &w, &ab) == 4)
-      cfg = ((tm * 1000L + am) * 10 + w) * 10 + ab;
-  }
-  return cfg;
-}
-
-#define SF_CFG(tm, am, w, ab) ((((tm) * 1000L + (am)) * 10 + (w)) * 10 + (ab))
-#define SF_CASE(tm, am, w, ab) \
-  case SF_CFG(tm, am, w, ab):  \
-    return launch<CIN, COUT, tm, am, w, ab>(a, bal)
-#define SF_CASE_W(tm, am, w) \
-  case SF_CFG(tm, am, w, 3):   \
-    return launch_wide<CIN, COUT, tm, am, w>(a, bal)  // "abuf" 3 = the wide kernel
-
-// Experiment hook: SF_CONV_DIRECT="mb,d1[,mincin,maxcin]" sends 27-offset layers with cin in the
-// range (default: all that are instantiated) to the direct kernel.
-int env_direct(int cin) {
-  static int cfg = -2, lo = 0, hi = 1 << 30;
-  if (cfg == -2) {
-    cfg = -1;
-    const char *e = getenv("SF_CONV_DIRECT");
-    int mb, d1;
-    if (e) {
-      int n = sscanf(e, "%d,%d,%d,%d", &mb, &d1, &lo, &hi);
-      if (n >= 2) cfg = mb * 10 + d1;
-      if (n < 4) hi = 1 << 30;
-      if (n < 3) lo = 0;
-    }
-  }
-  return (cin >= lo && cin <= hi) ? cfg : -1;
-}
-
+// The tile of each shape is the measured best of the sweeps recorded in DESIGN.md (tile rows,
+// gather chunk, waves, general / wide kernel, balanced or plain tiling).
 template <int CIN, int COUT>
 int launch_cfg(const ConvArgs &a) {
-  if constexpr (CIN <= 64 && COUT <= 64 && (COUT == CIN || COUT == 2 * CIN)) {
-    if (a.K == 27) {
-      int d = env_direct(CIN);
-      // measured (tools/sweep_direct.sh): the direct kernel wins for the narrow SubM layers
-      if (d == -1 && getenv("SF_CONV_DIRECT") == nullptr && CIN <= 32 && COUT <= 32) d = 12;
-      switch (d) {
-        case 12: return launch_direct<CIN, COUT, 1, 2>(a);
-        case 13: return launch_direct<CIN, COUT, 1, 3>(a);
-        case 14: return launch_direct<CIN, COUT, 1, 4>(a);
-        case 21: return launch_direct<CIN, COUT, 2, 1>(a);
-      }
-    }
+  // the narrow 27-offset layers whose table is too large for the narrow kernel: direct kernel
+  if constexpr (CIN <= 32 && COUT <= 32 && (COUT == CIN || COUT == 2 * CIN)) {
+    if (a.K == 27) return launch_direct<CIN, COUT, 1, 2>(a);
   }
-  // shapes of the SparseEncoder's wide stages get the tuning variants
+  // shapes of the SparseEncoder's wide stages
   constexpr bool big = CIN >= 32 && (COUT == CIN || COUT == 2 * CIN);
-  if constexpr (big) {
-    long cfg = env_cfg();
-    int bal = 0;
-    if (cfg < 0) {  // measured best per shape (tools/sweep_conv.sh); "abuf" 3 = wide kernel
-      bal = 1;
-      if (CIN >= 128) {
-        cfg = SF_CFG(96, 64, 8, 3);
-      } else if (COUT >= 128) {
-        cfg = SF_CFG(68, 64, 8, 3);
-        bal = 0;
-      } else if (COUT >= 64) {  // 32-row chunks, plain 64-row tiles: 0.775 vs 0.807 ms per 4 layers
-        cfg = SF_CFG(64, 32, 4, 3);
-        bal = 0;
-      } else {
-        cfg = SF_CFG(80, 64, 4, 1);
-      }
-    }
-    switch (cfg) {
-      SF_CASE(64, 64, 4, 2);
-      SF_CASE(64, 64, 4, 1);
-      SF_CASE(64, 64, 8, 1);
-      SF_CASE(64, 48, 4, 1);
-      SF_CASE(64, 48, 8, 1);
-      SF_CASE(68, 64, 8, 1);
-      SF_CASE(80, 48, 8, 1);
-      SF_CASE(80, 64, 4, 1);
-      SF_CASE(88, 64, 4, 1);
-      SF_CASE(96, 48, 4, 1);
-      SF_CASE(96, 64, 8, 1);
-      SF_CASE(128, 64, 8, 1);
-      SF_CASE_W(48, 32, 4);
-      SF_CASE_W(64, 32, 4);
-      SF_CASE_W(64, 64, 2);
-      SF_CASE_W(96, 64, 2);
-      SF_CASE_W(64, 64, 4);
-      SF_CASE_W(64, 48, 4);
-      case SF_CFG(64, 48, 4, 4):  // "abuf" 4 = wide kernel held to 3 waves per SIMD (3 blocks per CU)
-        return launch_wide<CIN, COUT, 64, 48, 4, 3>(a, bal);
-      case SF_CFG(72, 48, 4, 4):
-        return launch_wide<CIN, COUT, 72, 48, 4, 3>(a, bal);
-      SF_CASE_W(80, 64, 4);
-      SF_CASE_W(88, 64, 4);
-      SF_CASE_W(96, 48, 4);
-      SF_CASE_W(64, 64, 8);
-      SF_CASE_W(68, 64, 8);
-      SF_CASE_W(96, 64, 8);
-      SF_CASE_W(128, 64, 8);
-    }
-    sf_set_error("unknown SF_CONV_CFG %ld", cfg);
-    return SF_ERR_BAD_ARG;
-  } else {
+  if constexpr (!big) {
     return launch<CIN, COUT, 64, 64, 4, 2>(a, 0);
+  } else if constexpr (CIN >= 128) {
+    return launch_wide<CIN, COUT, 96, 64, 8>(a, 1);
+  } else if constexpr (COUT >= 128) {
+    return launch_wide<CIN, COUT, 68, 64, 8>(a, 0);
+  } else if constexpr (COUT >= 64) {  // 32-row chunks, plain 64-row tiles: 0.775 vs 0.807 ms per 4 layers
+    return launch_wide<CIN, COUT, 64, 32, 4>(a, 0);
+  } else {
+    return launch<CIN, COUT, 80, 64, 4, 1>(a, 1);
   }
-}
-#undef SF_CASE
-#undef SF_CASE_W
-
-// Experiment hook: SF_CONV_NARROW=0 sends the narrow layers to the older direct kernel (A/B runs).
-bool env_legacy_narrow() {
-  static int v = -1;
-  if (v < 0) {
-    const char *e = getenv("SF_CONV_NARROW");
-    v = (e && atoi(e) == 0) ? 1 : 0;
-  }
-  return v == 1;
 }
 
 template <int CIN>
@@ -1186,7 +1076,7 @@ extern "C" int sf_sparse_conv_f32(const float *features_in, int n_in_bound, int 
   const bool small_table = feat_bytes < (1ll << 31);
   ConvArgs a{features_in, small_table ? (unsigned)feat_bytes : 0u, nbr, nbr_stride, K, k_first,
              w_packed, scale, shift, residual, relu, out, n_out_dev, n_out_bound, st};
-  if (small_table && !env_legacy_narrow()) {  // the narrow 3x3x3 layers have a kernel of their own
+  if (small_table) {  // the narrow 3x3x3 layers have a kernel of their own
     const int rc = sf_narrow_conv_f32(cin_padded, cout, a);
     if (rc <= 0) return rc;
   }

@@ -167,16 +167,6 @@ int launch_narrow(const SfConvArgs &a) {
   return SF_OK;
 }
 
-// Experiment hook: SF_CONV_NARROW32=0 keeps the 32 -> 32 layers on the older direct kernel.
-bool env_narrow32() {
-  static int v = -1;
-  if (v < 0) {
-    const char *e = getenv("SF_CONV_NARROW32");
-    v = (e && atoi(e) == 0) ? 0 : 1;
-  }
-  return v == 1;
-}
-
 }  // namespace
 
 // Returns SF_OK after a launch, 1 when the shape is not one of this kernel's (the caller then
@@ -194,7 +184,7 @@ int sf_narrow_conv_f32(int cin_padded, int cout, const SfConvArgs &a) {
   SF_NARROW(16, 32, 9, 4)
   SF_NARROW(8, 32, 9, 4)
   // 32 -> 32: the filter bank is 108 KB, one 16-wave workgroup per CU shares it
-  if (env_narrow32()) { SF_NARROW(32, 32, 5, 16) }
+  SF_NARROW(32, 32, 5, 16)
 #undef SF_NARROW
   return 1;
 }

@@ -904,15 +904,6 @@ int launch_ordered(const OrdArgs &a) {
   return SF_OK;
 }
 
-bool env_dma() {
-  static int v = -1;
-  if (v < 0) {
-    const char *e = getenv("SF_ORD_DMA");
-    v = (e && atoi(e) == 0) ? 0 : 1;
-  }
-  return v == 1;
-}
-
 template <int CIN, int COUT, int CG, int WAVES, int MINB>
 int launch_dma(const OrdArgs &a) {
   auto kern = conv_f32_dma_kernel<CIN, COUT, CG, WAVES, MINB>;
@@ -938,20 +929,14 @@ int dispatch_ordered(int cout, const OrdArgs &a) {
   switch (cout) {
     case 16: return launch_ordered<CIN, 16, 1, 4, 2>(a);
     case 32: return launch_ordered<CIN, 32, 2, 4, 2>(a);
-    // (one filter set everywhere it was measured: 64 -> 64 141 vs 143 us; 3 workgroups per CU spill)
-    // SF_ORD_DMA=0 keeps the register-staged kernel (A/B switch; both are tested)
+    // The two square wide shapes run on the LDS-DMA kernel (64 -> 64: 136 vs 141 us for the
+    // register-staged kernel with one filter set; 128 -> 128: 184 vs 192 us); the others keep the
+    // register-staged kernel.
     case 64:
-      if constexpr (CIN == 64) {
-        if (env_dma()) return launch_dma<CIN, 64, 4, 4, 3>(a);      // 136 vs 141 us
-      }
-      return launch_ordered<CIN, 64, 4, 4, 2, 1>(a);
+      if constexpr (CIN == 64) return launch_dma<CIN, 64, 4, 4, 3>(a);
+      else return launch_ordered<CIN, 64, 4, 4, 2, 1>(a);
     case 128:
-      // (one filter set: 200 instead of 230 VGPRs, 194 vs 200 us; four waves with two column
-      // blocks each spill at 256)
-      if constexpr (CIN >= 128) {
-        if (env_dma()) return launch_dma<CIN, 128, 8, 8, 1>(a);     // 184 vs 192 us
-        return launch_ordered<CIN, 128, 8, 8, 1, 1>(a);
-      }
+      if constexpr (CIN >= 128) return launch_dma<CIN, 128, 8, 8, 1>(a);
       else return launch_ordered<CIN, 128, 4, 4, 2>(a);
   }
   sf_set_error("unsupported cout=%d (16, 32, 64 or 128)", cout);

@@ -142,23 +142,24 @@ class Rulebook:
         return self._pairs
 
 
-_ORDERED_DEFAULT = '64x64,128x128'   # measured: tools/ab_layers.sh, bench.py
+# fp32 layer shapes (padded CIN x COUT) of SubM rulebooks that run on the mask-ordered kernel: the
+# measured winners (tools/ab_layers.sh, bench.py).  'all' / 'none' / a comma list; a
+# module attribute so that a test or an A/B tool can set it before a LidarBackbone is built.
+ORDERED_SHAPES = '64x64,128x128'
 
 
 def use_ordered(cin_padded, cout, subm=True):
     """Whether an fp32 layer of this shape runs on the mask-ordered kernel
-    (sf_sparse_conv_f32_ordered) instead of the pair-compacting / direct ones.  SF_CONV_ORDERED
-    overrides: 'all', 'none' or a comma list of CINxCOUT shapes.  By default only SubM layers
-    qualify: their rulebook (and so the plan the kernel needs) is shared by the four convolutions
-    of a stage, a strided rulebook is used once and its sort would cost more than it saves."""
-    import os
-    sel = os.environ.get('SF_CONV_ORDERED')
-    if sel is None:
-        sel = _ORDERED_DEFAULT if subm else ''
-    sel = sel.strip().lower()
-    if cin_padded < 16 or sel in ('', 'none', '0'):
+    (sf_sparse_conv_f32_ordered) instead of the pair-compacting / direct ones (ORDERED_SHAPES).
+    Unless ORDERED_SHAPES is 'all', only SubM layers qualify: their rulebook (and so the plan the
+    kernel needs) is shared by the four convolutions of a stage, a strided rulebook is used once
+    and its sort would cost more than it saves."""
+    sel = ORDERED_SHAPES.strip().lower()
+    if sel != 'all' and not subm:
         return False
-    if sel in ('all', '1'):
+    if cin_padded < 16 or sel in ('', 'none'):
+        return False
+    if sel == 'all':
         return True
     return f'{cin_padded}x{cout}' in sel.split(',')
 

@@ -156,12 +156,13 @@ def test_many_tiles_per_workgroup(dev, oracle, cin, cout, cap, batch):
 
 
 def test_pipeline_with_the_ordered_kernel(dev, oracle, monkeypatch):
-    """LidarBackbone with every eligible layer on the ordered kernel (SF_CONV_ORDERED=all), device
+    """LidarBackbone with every eligible layer on the ordered kernel (spconv.ORDERED_SHAPES = 'all'), device
     row counts, captured in a HIP graph: BEV map against the oracle."""
     from sparsefusion_amd.pipeline import LidarBackbone
     from test_gpu_conv import make_encoder
     from test_gpu_pipeline import VL, oracle_bev
-    monkeypatch.setenv('SF_CONV_ORDERED', 'all')
+    from sparsefusion_amd import spconv
+    monkeypatch.setattr(spconv, 'ORDERED_SHAPES', 'all')
     enc, sd, cfg = make_encoder(dev, 5, 21)
     frames = [small_points(700 + b, 3000 + 800 * b) for b in range(2)]
     pts = [to_dev(p, dev) for p in frames]

@@ -79,18 +79,19 @@ def test_conv_output_size_rule():
 
 
 def test_ordered_kernel_selection(monkeypatch):
-    """SF_CONV_ORDERED: which fp32 layer shapes run on the mask-ordered kernel (default: the 64- and
-    128-channel SubM shapes, where it measured faster end to end)."""
-    monkeypatch.delenv('SF_CONV_ORDERED', raising=False)
+    """spconv.ORDERED_SHAPES: which fp32 layer shapes run on the mask-ordered kernel (default: the
+    64- and 128-channel SubM shapes, where it measured faster end to end)."""
     assert spconv.use_ordered(64, 64) and spconv.use_ordered(128, 128)
     assert not spconv.use_ordered(32, 32) and not spconv.use_ordered(64, 128)
     assert not spconv.use_ordered(128, 128, subm=False)      # a strided rulebook is used once
-    monkeypatch.setenv('SF_CONV_ORDERED', '32x32,64x64')
+    monkeypatch.setattr(spconv, 'ORDERED_SHAPES', '32x32,64x64')
     assert spconv.use_ordered(64, 64) and spconv.use_ordered(32, 32)
     assert not spconv.use_ordered(128, 128) and not spconv.use_ordered(8, 16)
-    monkeypatch.setenv('SF_CONV_ORDERED', 'all')
+    assert not spconv.use_ordered(64, 64, subm=False)
+    monkeypatch.setattr(spconv, 'ORDERED_SHAPES', 'all')
     assert spconv.use_ordered(128, 64) and not spconv.use_ordered(8, 16)   # first layer: cin < 16
-    monkeypatch.setenv('SF_CONV_ORDERED', 'none')
+    assert spconv.use_ordered(64, 128, subm=False)
+    monkeypatch.setattr(spconv, 'ORDERED_SHAPES', 'none')
     assert not spconv.use_ordered(64, 64)
 
 

@@ -1,6 +1,6 @@
-# usage: tools/ab_layers.sh <tag> [ENV=VAL ...]   -- short bench with per-layer detail under the given env
+# usage: tools/ab_layers.sh <tag> [bench.py options ...]   -- short bench with per-layer detail
 tag=$1; shift
-env "$@" timeout -k 10 200 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --detail gpurun_out/d_$tag.json > gpurun_out/b_$tag.log 2>&1 || { tail -5 gpurun_out/b_$tag.log; exit 1; }
+timeout -k 10 200 python bench.py "$@" --steps 60 --warmup 10 --no-cpu-baseline --detail gpurun_out/d_$tag.json > gpurun_out/b_$tag.log 2>&1 || { tail -5 gpurun_out/b_$tag.log; exit 1; }
 python - <<PY
 import json
 line=json.loads(open('gpurun_out/b_$tag.log').read().strip().splitlines()[-1])

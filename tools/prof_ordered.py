@@ -1,7 +1,6 @@
 import sys, os, ctypes
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
-os.environ.setdefault('SF_CONV_ORDERED', '64x64,128x128')
 import bench
 from sparsefusion_amd import synth, _lib
 dev = torch.device('cuda:0')
