@@ -99,6 +99,41 @@ def layer_work(bb):
     return rows, counts
 
 
+def stage_work(bb, pts):
+    """ALGORITHMIC bytes of the stages that are not convolutions, for the LAST enqueued batch
+    (formulas of SURVEY 8d): voxelize = N F 4 read + M (max_pts F 4 + 12 + 4) write + M F 4 (fused
+    mean); a rulebook = 16 bytes per input coordinate read + 8 bytes per pair written (+ 16 per new
+    output coordinate of a strided rulebook); the 27 hash probes per row (8 bytes each) are listed
+    apart; a plan (no reference counterpart) = its table read once + the permuted table, row order
+    and headers written; dense = rows read once + the whole map written."""
+    counts = bb.counts.tolist()
+    n_pts = int(sum(p.shape[0] for p in pts))
+    F = int(pts[0].shape[1])
+    M = counts[0]
+    out = {'voxelize': dict(points=n_pts, voxels=M,
+                            bytes=n_pts * F * 4.0 + M * (bb.mp * F * 4.0 + 12 + 4) + M * F * 4.0)}
+    si = 0
+    for i, rb in enumerate(bb.rulebooks):
+        n_in, n_out = counts[rb['src']], counts[rb['dst']]
+        P = int((rb['nbr'][:, :n_out] >= 0).sum().item())
+        if not rb['subm']:
+            si += 1
+        name = (f'subm_rulebook_set{rb["dst"]}' if rb['subm'] else f'strided_rulebook_{si}')
+        out[name] = dict(rulebook=i, K=rb['K'], n_in=n_in, n_out=n_out, pairs=P,
+                         bytes=n_in * 16.0 + P * 8.0 + (0 if rb['subm'] else n_out * 16.0),
+                         probe_bytes=(rb['K'] * n_out * 8.0 if rb['subm'] else rb['K'] * n_in * 8.0))
+        if 'order' in rb:
+            out[f'plan_set{rb["dst"]}'] = dict(rulebook=i, rows=n_out,
+                                              bytes=2.0 * rb['K'] * n_out * 4 + n_out * 4.0 +
+                                              (n_out + 63) // 64 * 32 * 4.0)
+    o = bb.sets[bb.out_set]
+    D, H, W = o['shape']
+    n_o = counts[bb.out_set]
+    out['dense'] = dict(rows=n_o, bytes=n_o * bb.out_channels * 4.0 + n_o * 16.0 +
+                        bb.B * bb.out_channels * D * H * W * 4.0)
+    return out
+
+
 def time_layers(bb, pts, vf, iters=5, busy=None):
     """Mean launch duration of every conv layer, HIP events on the launch stream (eager).
 
@@ -483,10 +518,15 @@ def main():
                 bb.enqueue(fr, vf)
                 torch.cuda.synchronize()
                 work_f, counts_f = layer_work(bb)
+                stage_f = stage_work(bb, fr)
                 if fi == 0:
-                    ms, work, counts = ms_f, work_f, counts_f
+                    ms, work, counts, stages = ms_f, work_f, counts_f, stage_f
                 else:
                     ms = ms + ms_f
+                    for k_, st_ in stage_f.items():
+                        for kk in st_:
+                            if kk not in ('rulebook', 'K'):
+                                stages[k_][kk] += st_[kk]
                     for w, wf in zip(work, work_f):
                         for k in ('pairs', 'n_out', 'flops', 'bytes'):
                             w[k] += wf[k]
@@ -494,6 +534,10 @@ def main():
             for w in work:
                 for k in ('pairs', 'n_out', 'flops', 'bytes'):
                     w[k] /= len(frames)
+            for st_ in stages.values():
+                for kk in st_:
+                    if kk not in ('rulebook', 'K'):
+                        st_[kk] /= len(frames)
             bb.enqueue(frames[0], vf)
             torch.cuda.synchronize()
             res = bb.results()
@@ -553,7 +597,7 @@ def main():
                           groups={f'{k[0]}x{k[1]}' + ('b' if k[2] else '') +
                                   ('' if k[3] == 27 else f'k{k[3]}') + ('' if k[4] else 's'): v
                                   for k, v in groups.items()},
-                          workspace_bytes=bb.memory_bytes())
+                          stages=stages, workspace_bytes=bb.memory_bytes())
 
         # ---- what the job computed, checked across ranks (outside the timed region) -------------
         # every batch of every rank must be present in the gathered table, and a batch recomputed
