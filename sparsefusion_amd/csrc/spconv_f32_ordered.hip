@@ -611,7 +611,8 @@ __global__ void __launch_bounds__(WAVES * 64, MINB)
 conv_f32_dma_kernel(const float *__restrict__ feat, unsigned feat_bytes, PlanView pv, int K,
                     int k_first, const f32x4 *__restrict__ wp, const float *__restrict__ scale,
                     const float *__restrict__ shift, const float *__restrict__ residual, int relu,
-                    float *__restrict__ out, const int *n_out_dev, int n_out_bound) {
+                    float *__restrict__ out, const int *n_out_dev, int n_out_bound,
+                    unsigned long long *__restrict__ wg_times) {
   constexpr int TM = kTileRows, T = CIN / 16, ROWB = CIN * 4, CH = CIN / 4;
   constexpr int NB = COUT / 16, NBW = NB / CG, RG = WAVES / CG, MBT = TM / 16, MBW = MBT / RG;
   constexpr int RPI = 1024 / ROWB;             // rows one DMA instruction covers
@@ -642,6 +643,7 @@ conv_f32_dma_kernel(const float *__restrict__ feat, unsigned feat_bytes, PlanVie
   const int G = gridDim.x, b = blockIdx.x;
   const int full = tiles / G, rem = tiles - full * G;
   const int my_n = full + ((((full & 1) ? G - 1 - b : b) < rem) ? 1 : 0);
+  if (wg_times && tid == 0) wg_times[b] = wall_clock64();
 
   f32x4 acc[MBW][NBW];
   f32x4 bf[NBW][T];
@@ -855,9 +857,11 @@ conv_f32_dma_kernel(const float *__restrict__ feat, unsigned feat_bytes, PlanVie
       phase(std::integral_constant<int, 2>{});
     } while (((iA | iB | iC | iD) >> 13) & 1);
   }
+  if (wg_times && tid == 0) wg_times[G + b] = wall_clock64();
 }
 
-unsigned long long *g_ord_prof = nullptr;   // diagnostic only, see sf_debug_ordered_profile
+unsigned long long *g_ord_prof = nullptr;
+unsigned long long *g_dma_wg_times = nullptr;   // diagnostic only, see sf_debug_dma_wg_times   // diagnostic only, see sf_debug_ordered_profile
 int g_ord_grid_cap = 0;                     // test hook, see sf_debug_ordered_grid_cap (0 = off)
 
 struct OrdArgs {
@@ -917,7 +921,7 @@ int launch_dma(const OrdArgs &a) {
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), 0, a.st, a.feat, a.feat_bytes,
                      plan_view(a.plan, a.n_out_bound), a.K, a.k_first,
                      reinterpret_cast<const f32x4 *>(a.wpk), a.scale, a.shift, a.residual, a.relu,
-                     a.out, a.n_out_dev, a.n_out_bound);
+                     a.out, a.n_out_dev, a.n_out_bound, g_dma_wg_times);
   SF_CHECK_LAUNCH();
   return SF_OK;
 }
@@ -1067,6 +1071,13 @@ extern "C" int sf_sparse_conv_f32_ordered(const float *features_in, int n_in_bou
 // [6] cycles in kernel, [7] waves, [8] 100 MHz ticks in kernel; NULL = off.
 extern "C" __attribute__((visibility("default"))) void sf_debug_ordered_profile(void *dev_buf16) {
   g_ord_prof = (unsigned long long *)dev_buf16;
+}
+
+// Diagnostic hook (not part of the documented ABI): a device buffer of 2 x 4096 uint64; every LDS-DMA
+// conv launch writes the 100 MHz wall clock at the start ([b]) and end ([grid + b]) of workgroup b
+// (tools/prof_dma_wg.py: how level the persistent workgroups finish).  NULL = off.
+extern "C" __attribute__((visibility("default"))) void sf_debug_dma_wg_times(void *dev_buf) {
+  g_dma_wg_times = (unsigned long long *)dev_buf;
 }
 
 // Test hook (not part of the documented ABI): limits the grid of the ordered / DMA kernels to `cap`

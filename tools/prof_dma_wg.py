@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""How level do the persistent workgroups of the LDS-DMA conv kernels finish?  Every launch of one
+eager frame stamps the 100 MHz wall clock at the start and end of each workgroup
+(sf_debug_dma_wg_times); printed per launch: kernel span, mean / percentiles of the workgroups'
+end times relative to the first start, and the share of workgroup-time spent waiting for the
+slowest one (1 - mean busy / span).
+
+    python tools/prof_dma_wg.py [--frame 0]
+"""
+import argparse
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from sparsefusion_amd import _lib, synth  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--frame', type=int, default=0)
+    args = ap.parse_args()
+    dev = torch.device('cuda:0')
+    pts = synth.nuscenes_frame(args.frame)
+    cfg, ecfg, sd, enc, bb = bench.build_backbone('nusc', dev, 1, pts.shape[0])
+    f = [torch.from_numpy(pts).to(dev)]
+    L = _lib.lib()
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    raw.sf_debug_dma_wg_times.argtypes = [ctypes.c_void_p]
+    buf = torch.zeros(2 * 4096, dtype=torch.int64, device=dev)
+    with torch.no_grad():
+        for _ in range(3):
+            bb.enqueue(f)
+        torch.cuda.synchronize()
+        real = L.sf_sparse_conv_f32_ordered
+
+        class Shim:
+            def __getattr__(self, n):
+                return getattr(L, n)
+        res = []
+
+        def wrapped(*a):
+            buf.zero_()
+            torch.cuda.synchronize()
+            raw.sf_debug_dma_wg_times(buf.data_ptr())
+            rc = real(*a)
+            torch.cuda.synchronize()
+            raw.sf_debug_dma_wg_times(None)
+            res.append((a[2], a[9], L.sf_last_conv_kernel().decode(), buf.cpu().numpy().copy()))
+            return rc
+        sh = Shim()
+        sh.__dict__['sf_sparse_conv_f32_ordered'] = wrapped
+        bb.L = sh
+        bb.enqueue(f)
+        torch.cuda.synchronize()
+    for cin, cout, kern, v in res:
+        g = int((v != 0).sum()) // 2      # starts at [0, g), ends at [g, 2 g)
+        st, en = v[:g].astype(np.float64), v[g:2 * g].astype(np.float64)
+        t0 = st.min()
+        span = (en.max() - t0) / 100.0
+        busy = (en - st) / 100.0
+        endr = (en - t0) / 100.0
+        print(f'{kern}: grid {g} span {span:.1f} us | start spread {(st.max() - t0) / 100:.1f} us | '
+              f'end p10 {np.percentile(endr, 10):.1f} p50 {np.percentile(endr, 50):.1f} p90 {np.percentile(endr, 90):.1f} '
+              f'max {endr.max():.1f} | mean busy {busy.mean():.1f} us = {busy.mean() / span:.1%} of the span')
+
+
+if __name__ == '__main__':
+    main()
