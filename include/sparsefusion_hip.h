@@ -83,7 +83,7 @@ SF_API int sf_hard_voxelize(const float *points, int n, int f, const float voxel
                             size_t workspace_bytes, void *stream);
 
 /* Bytes of the static device scratch behind sf_hard_voxelize_static (per GPU). */
-#define SF_STATIC_SCRATCH_BYTES (32u << 20)
+#define SF_STATIC_SCRATCH_BYTES (36u << 20)
 
 /* sf_hard_voxelize for callers that CANNOT ALLOCATE device memory (code under HIP graph capture,
  * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference (its op

@@ -9,12 +9,18 @@
 //   fill    : hash slots (key, first point) <- (EMPTY, INT_MAX)              [8 bytes per slot]
 //   insert  : per point: coordinate -> hash slot (atomicCAS on the key), atomicMin of the point
 //             index into the slot's `first` word, which sits next to the key (one 64-byte line
-//             serves both); the point remembers its slot
+//             serves both); the point remembers its slot.  Consecutive points of one voxel (a
+//             LiDAR ring sweeping over a near surface) form a RUN inside a wave: only the head of
+//             a run offers its index, and the max_points-th point of a run posts its index as the
+//             voxel's BOUND (at least max_points points of the voxel lie at or below it)
 //   count   : flag "point i is the first point of its voxel" (first[slot] == i), block sums
 //   assign  : exclusive scan of the flags = voxel id in first-point order; the point whose
 //             voxel id equals max_voxels is the cut (reference `break`); writes coors, slot -> voxel
 //             id, and opens the voxel's point list (INT_MAX) in a table indexed by VOXEL ID
-//   collect : per point below the cut whose voxel survived: bounded sorted insert of the point
+//   collect : per point below the cut whose voxel survived (and, where the voxel has a bound, at
+//             or below it: a voxel that swallows 30 000 points of a frame -- a return right at the
+//             sensor -- otherwise has them all cascade through one 40-byte list at once, measured
+//             4.2 ms for one launch): bounded sorted insert of the point
 //             index into the voxel's list of the max_points SMALLEST indices (a cascade of
 //             atomicMin: an entry keeps the min of everything offered to it and passes the rest on;
 //             the multiset is conserved, so the result is order independent)
@@ -65,7 +71,8 @@ __global__ void dynamic_voxelize_kernel(const float *__restrict__ points, int n,
 }
 
 // misc words: [0] cut point index, [1] voxel_num of this call, [2] overflow, [3] base row
-// slot table: kf[2*slot] = key, kf[2*slot + 1] = smallest point index of the voxel
+// slot table: kf[2*slot] = key, kf[2*slot + 1] = smallest point index of the voxel; the bound words
+// (one per slot, unsigned: both fill values read as "no bound") follow the table and share its fill
 __global__ void vox_fill_kernel(uint2 *__restrict__ kf, long long n_slots, int *__restrict__ misc,
                                 const int *__restrict__ row_count_dev) {
   long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -81,37 +88,63 @@ __global__ void vox_fill_kernel(uint2 *__restrict__ kf, long long n_slots, int *
   }
 }
 
-__global__ void vox_insert_kernel(const float *__restrict__ points, int n, int f, VoxParams vp,
-                                  uint32_t *__restrict__ kf, uint32_t mask, int *__restrict__ pslot,
+__global__ void vox_insert_kernel(const float *__restrict__ points, int n, int f, int max_points,
+                                  VoxParams vp, uint32_t *__restrict__ kf, uint32_t mask,
+                                  uint32_t *__restrict__ sbound, int *__restrict__ pslot,
                                   int *__restrict__ overflow_dev) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+  const int lane = threadIdx.x & 63;
+  // (the loop bound is the same for the lanes of a wave: the run detection below shuffles)
+  for (int base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
+    const int i = base + threadIdx.x;
     int c[3];
-    if (!point_coor(points + (size_t)i * f, vp, c)) {
-      pslot[i] = -1;
-      continue;
+    uint32_t key = SF_EMPTY_KEY;   // never a voxel's key (the grid volume is below 2^32 - 1)
+    if (i < n && point_coor(points + (size_t)i * f, vp, c))
+      key = ((uint32_t)c[0] * (uint32_t)vp.grid[1] + (uint32_t)c[1]) * (uint32_t)vp.grid[0] + (uint32_t)c[2];
+    const bool valid = key != SF_EMPTY_KEY;
+    // runs of consecutive lanes in one voxel: the head probes the table for the whole run and
+    // holds the run's smallest index
+    const uint32_t prev = __shfl_up(key, 1, 64);
+    const bool head = lane == 0 || key != prev || !valid;
+    const unsigned long long heads = __ballot(head);
+    int leader = 63 - __builtin_clzll(heads & ((2ull << lane) - 1ull));
+    bool post = lane - leader == max_points - 1;
+    // up to two voxels that continue a run in this wave are matched over the WHOLE wave (a ring that
+    // alternates between two voxels, runs broken by a stray point): one probe, one offer per voxel
+    // and wave, and the bound from all of the wave's lanes in the voxel
+    unsigned long long multi = __ballot(valid && !head);
+    for (int it = 0; it < 2 && multi; ++it) {
+      const uint32_t k_hot = __shfl(key, __builtin_ctzll(multi), 64);
+      const unsigned long long m = __ballot(key == k_hot);
+      if (key == k_hot) {
+        leader = __builtin_ctzll(m);
+        post = __popcll(m & ((1ull << lane) - 1ull)) == max_points - 1;
+      }
+      multi &= ~m;
     }
-    const uint32_t key = ((uint32_t)c[0] * (uint32_t)vp.grid[1] + (uint32_t)c[1]) *
-                             (uint32_t)vp.grid[0] + (uint32_t)c[2];
-    uint32_t slot = sf_scatter_slot(key, mask);
     int found = -1;
-    for (uint32_t probe = 0; probe <= mask; ++probe) {
-      uint32_t cur = kf[2 * (size_t)slot];
-      if (cur == SF_EMPTY_KEY) {
-        cur = atomicCAS(&kf[2 * (size_t)slot], SF_EMPTY_KEY, key);
-        if (cur == SF_EMPTY_KEY) cur = key;
+    if (valid && leader == lane) {
+      uint32_t slot = sf_scatter_slot(key, mask);
+      for (uint32_t probe = 0; probe <= mask; ++probe) {
+        uint32_t cur = kf[2 * (size_t)slot];
+        if (cur == SF_EMPTY_KEY) {
+          cur = atomicCAS(&kf[2 * (size_t)slot], SF_EMPTY_KEY, key);
+          if (cur == SF_EMPTY_KEY) cur = key;
+        }
+        if (cur == key) {
+          found = (int)slot;
+          break;
+        }
+        slot = (slot + 1) & mask;
       }
-      if (cur == key) {
-        found = (int)slot;
-        break;
-      }
-      slot = (slot + 1) & mask;
+      if (found < 0 && overflow_dev) *overflow_dev = 1;  // cannot happen with capacity >= n; a guard
     }
-    pslot[i] = found;
-    if (found < 0) {  // cannot happen with capacity >= n; kept as a guard
-      if (overflow_dev) *overflow_dev = 1;
-      continue;
+    found = __shfl(found, leader, 64);
+    if (!valid) found = -1;
+    if (i < n) pslot[i] = found;
+    if (found >= 0) {
+      if (leader == lane) atomicMin(reinterpret_cast<int *>(kf) + 2 * (size_t)found + 1, i);
+      if (post) atomicMin(&sbound[found], (uint32_t)i);
     }
-    atomicMin(reinterpret_cast<int *>(kf) + 2 * (size_t)found + 1, i);
   }
 }
 
@@ -123,6 +156,8 @@ __device__ __forceinline__ bool is_first_point(int i, int n, const int *__restri
   if (slot < 0) return false;
   return (int)kf[2 * (size_t)slot + 1] == i;
 }
+
+constexpr int kBoundedBit = 1 << 30;
 
 __global__ void __launch_bounds__(kThreads)
 vox_count_kernel(int n, const int *__restrict__ pslot, const uint32_t *__restrict__ kf,
@@ -147,7 +182,8 @@ vox_count_kernel(int n, const int *__restrict__ pslot, const uint32_t *__restric
 
 __global__ void __launch_bounds__(kThreads)
 vox_assign_kernel(int n, int max_points, int max_voxels, VoxParams vp, const int *__restrict__ pslot,
-                  const uint32_t *__restrict__ kf, const int *__restrict__ bsum, int nblk,
+                  const uint32_t *__restrict__ kf, const uint32_t *__restrict__ sbound,
+                  const int *__restrict__ bsum, int nblk,
                   int *__restrict__ slot_vid, int *__restrict__ lists, int *__restrict__ coors,
                   int coors_stride, int batch_idx, int rows_capacity, int *__restrict__ misc,
                   int *__restrict__ row_count_dev, int *__restrict__ overflow_dev) {
@@ -174,7 +210,9 @@ vox_assign_kernel(int n, int max_points, int max_voxels, VoxParams vp, const int
     if (!((flags >> e) & 1u)) continue;
     if (max_voxels >= 0 && vid == max_voxels) misc[0] = base + e;  // the reference's `break`
     const bool keep = max_voxels < 0 || vid < max_voxels;
-    slot_vid[slots[e]] = keep ? vid : -1;
+    // bit 30: the voxel has a bound (vox_collect then reads it; the fill values have bits 0-30 set)
+    const bool bounded = (sbound[slots[e]] & 0x7FFFFFFFu) != 0x7FFFFFFFu;
+    slot_vid[slots[e]] = keep ? (vid | (bounded ? kBoundedBit : 0)) : -1;
     if (keep) {
       int *list = lists + (size_t)vid * max_points;
       list[0] = base + e;   // the first point is the smallest index: it opens the list
@@ -216,15 +254,18 @@ vox_assign_kernel(int n, int max_points, int max_voxels, VoxParams vp, const int
 // cascade too early, never too late).  MP == 0: any max_points, entry by entry.
 template <int MP>
 __global__ void vox_collect_kernel(int n, int max_points, const int *__restrict__ pslot,
-                                   const int *__restrict__ slot_vid, const int *__restrict__ misc,
-                                   int *__restrict__ lists) {
+                                   const int *__restrict__ slot_vid, const uint32_t *__restrict__ sbound,
+                                   const int *__restrict__ misc, int *__restrict__ lists) {
   const int cut = misc[0];
   const int stop = cut < n ? cut : n;   // points from the cut on belong to no voxel
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < stop; i += gridDim.x * blockDim.x) {
     const int slot = pslot[i];
     if (slot < 0) continue;
-    const int vid = slot_vid[slot];
-    if (vid < 0) continue;
+    const int sv = slot_vid[slot];
+    if (sv < 0) continue;
+    // max_points points of the voxel lie at or below its bound: this one cannot be among them
+    if ((sv & kBoundedBit) && (uint32_t)i > sbound[slot]) continue;
+    const int vid = sv & (kBoundedBit - 1);
     int *list = lists + (size_t)vid * max_points;
     int v = i;
     int s0 = 0;
@@ -366,6 +407,7 @@ size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct VoxWorkspace {
   uint32_t *kf;        // (key, first point) per hash slot
+  uint32_t *sbound;    // bound per hash slot, directly behind kf (one fill covers both)
   int *lists, *pslot, *bsum, *misc, *slot_vid;
   long long cap;
   int nblk;
@@ -384,7 +426,9 @@ VoxWorkspace carve(void *ws, int n, int max_points) {
   size_t off = 0;
   char *b = (char *)ws;
   w.kf = (uint32_t *)(b + off);
-  off += align_up((size_t)cap * 8);
+  off += (size_t)cap * 8;              // (cap is a power of two >= 1024: no padding in between)
+  w.sbound = (uint32_t *)(b + off);
+  off += align_up((size_t)cap * 4);
   w.slot_vid = (int *)(b + off);
   off += align_up((size_t)cap * 4);
   w.lists = (int *)(b + off);          // by voxel id: at most one voxel per point
@@ -450,7 +494,7 @@ int hard_voxelize_impl(const float *points, int n, int f, const float voxel_size
                        int rows_capacity, int *overflow_dev, int *voxel_num_host, void *workspace,
                        size_t workspace_bytes, hipStream_t st, const SfVoxFuse *fuse = nullptr) {
 
-  SF_CHECK_ARG(n >= 0 && f >= 3, "bad shape n=%d f=%d (need f >= 3)", n, f);
+  SF_CHECK_ARG(n >= 0 && n < (1 << 30) && f >= 3, "bad shape n=%d f=%d (need f >= 3, n < 2^30)", n, f);
   SF_CHECK_ARG(max_points >= 1, "max_points=%d: the hard path needs max_points >= 1 "
                "(use sf_dynamic_voxelize for -1)", max_points);
   SF_CHECK_ARG(max_voxels >= -1, "max_voxels=%d", max_voxels);
@@ -471,13 +515,14 @@ int hard_voxelize_impl(const float *points, int n, int f, const float voxel_size
   SF_CHECK_ARG(n == 0 || points, "points is NULL");
 
   if (!(fuse && fuse->tables_ready && n > 0)) {
-    hipLaunchKernelGGL(vox_fill_kernel, dim3(sf_grid(w.cap / 2, kThreads)), dim3(kThreads), 0, st,
-                       reinterpret_cast<uint2 *>(w.kf), w.cap, w.misc, (const int *)row_count_dev);
+    // table + bound words: 3 * cap words = (cap + cap / 2) slots' worth of fill
+    hipLaunchKernelGGL(vox_fill_kernel, dim3(sf_grid(3 * w.cap / 4, kThreads)), dim3(kThreads), 0, st,
+                       reinterpret_cast<uint2 *>(w.kf), w.cap + w.cap / 2, w.misc, (const int *)row_count_dev);
     SF_CHECK_LAUNCH();
   }
   if (n > 0) {
     hipLaunchKernelGGL(vox_insert_kernel, dim3(sf_grid(n, kThreads)), dim3(kThreads), 0, st, points,
-                       n, f, vp, w.kf, (uint32_t)(w.cap - 1), w.pslot, overflow_dev);
+                       n, f, max_points, vp, w.kf, (uint32_t)(w.cap - 1), w.sbound, w.pslot, overflow_dev);
     SF_CHECK_LAUNCH();
     hipLaunchKernelGGL(vox_count_kernel, dim3(w.nblk), dim3(kThreads), 0, st, n,
                        (const int *)w.pslot, (const uint32_t *)w.kf, w.bsum, w.misc,
@@ -485,7 +530,7 @@ int hard_voxelize_impl(const float *points, int n, int f, const float voxel_size
     SF_CHECK_LAUNCH();
     hipLaunchKernelGGL(vox_assign_kernel, dim3(w.nblk), dim3(kThreads), 0, st, n, max_points,
                        max_voxels, vp, (const int *)w.pslot, (const uint32_t *)w.kf,
-                       (const int *)w.bsum, w.nblk, w.slot_vid, w.lists, coors, coors_stride,
+                       (const uint32_t *)w.sbound, (const int *)w.bsum, w.nblk, w.slot_vid, w.lists, coors, coors_stride,
                        batch_idx, rows_capacity, w.misc, row_count_dev, overflow_dev);
     SF_CHECK_LAUNCH();
     auto collect = max_points == 10 ? vox_collect_kernel<10>
@@ -494,7 +539,8 @@ int hard_voxelize_impl(const float *points, int n, int f, const float voxel_size
     if (max_points == 20) collect = vox_collect_kernel<20>;
     if (max_points == 32) collect = vox_collect_kernel<32>;
     hipLaunchKernelGGL(collect, dim3(sf_grid(n, kThreads)), dim3(kThreads), 0, st, n, max_points,
-                       (const int *)w.pslot, (const int *)w.slot_vid, (const int *)w.misc, w.lists);
+                       (const int *)w.pslot, (const int *)w.slot_vid, (const uint32_t *)w.sbound,
+                       (const int *)w.misc, w.lists);
     SF_CHECK_LAUNCH();
     long long bound_v = (max_voxels >= 0 && max_voxels < n) ? max_voxels : n;
     const bool fused_wr = voxels && (num_points_per_voxel || mean) && (max_points == 10 || max_points == 5);
@@ -573,7 +619,7 @@ int sf_int_hard_voxelize(const float *points, int n, int f, const float voxel_si
 void sf_int_vox_table(void *workspace, int n, int max_points, uint32_t **table, size_t *words) {
   VoxWorkspace w = carve(workspace, n, max_points);
   *table = w.kf;
-  *words = (size_t)w.cap * 2;
+  *words = (size_t)w.cap * 3;   // slot table + bound words
 }
 
 extern "C" int sf_hard_voxelize(const float *points, int n, int f, const float voxel_size[3],

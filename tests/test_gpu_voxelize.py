@@ -50,6 +50,31 @@ def test_small_frames_caps(dev, oracle, n, mp, mv):
     check_equal(pts, SMALL_VOXEL, SMALL_RANGE, mp, mv, dev, oracle)
 
 
+@pytest.mark.parametrize('mp,mv', [(10, 20000), (5, 20000), (3, 20000), (20, 20000), (10, 40), (1, 20000)])
+def test_crowded_voxels(dev, oracle, mp, mv):
+    """A few voxels swallow most of the cloud (a return right at the sensor): long runs of
+    consecutive points in one voxel, two voxels alternating point by point, runs broken by strays,
+    and the same voxels again later in the scan.  The run / bound shortcuts of vox_insert and
+    vox_collect must keep exactly the first max_points points of each voxel, in scan order."""
+    rs = np.random.RandomState(77)
+    base = small_points(9, 6000)
+    cells = np.array([[0.3, 0.3, 0.1], [-2.1, 1.7, 0.5], [3.3, -0.9, -0.7]], np.float32)
+
+    def near(ci, n):      # n points inside the voxel of cells[ci]
+        p = np.zeros((n, base.shape[1]), np.float32)
+        p[:, :3] = cells[ci] + rs.uniform(-0.01, 0.01, (n, 3)).astype(np.float32)
+        p[:, 3:] = rs.rand(n, base.shape[1] - 3).astype(np.float32)
+        return p
+    alt = np.empty((600, base.shape[1]), np.float32)
+    alt[0::2], alt[1::2] = near(1, 300), near(2, 300)
+    broken = near(0, 900)
+    broken[::7] = base[:129]                       # a stray point every 7th slot of a run
+    pts = np.concatenate([base[:500], near(0, 3000), base[500:900], alt, base[900:2500], broken,
+                          near(1, 70), base[2500:], near(2, 5000)])
+    check_equal(pts, SMALL_VOXEL, SMALL_RANGE, mp, mv, dev, oracle)
+    check_equal(pts[::-1].copy(), SMALL_VOXEL, SMALL_RANGE, mp, mv, dev, oracle)
+
+
 def test_edge_values(dev, oracle):
     pts = small_points(5, 600)
     pts[10, 0] = np.nan
