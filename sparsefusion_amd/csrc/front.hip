@@ -138,12 +138,14 @@ extern "C" int sf_lidar_front(const SfFrontDesc *d, void *stream) {
     long long vol = (long long)d->batch * s0.shape[0] * s0.shape[1] * s0.shape[2];
     SF_CHECK_ARG(vol > 0 && vol < 0xFFFFFFFFll, "batch*D*H*W of set 0 does not fit 32-bit keys");
   }
-  for (int b = 0; b < d->batch; ++b) {
-    rc = sf_int_hard_voxelize(
-        d->points[b], d->num_points[b], d->num_features, d->voxel_size, d->coors_range, d->max_points,
-        d->max_voxels, d->voxels, s0.indices, 4, b, d->num_points_per_voxel, d->mean, d->mean_features,
-        d->mean_stride, d->counts_dev, s0.bound, overflow_dev, nullptr,
-        (char *)d->vox_workspace + (size_t)b * d->vox_workspace_bytes, d->vox_workspace_bytes, st, &vf);
+  {   // every sample through the same launches (blockIdx.y = sample), kVoxBatch at a time
+    SF_CHECK_ARG(d->batch <= 64, "batch %d: at most 64 samples per call", d->batch);
+    void *wss[64];
+    for (int b = 0; b < d->batch; ++b) wss[b] = (char *)d->vox_workspace + (size_t)b * d->vox_workspace_bytes;
+    rc = sf_int_hard_voxelize(d->batch, d->points, d->num_points, d->num_features, d->voxel_size,
+                              d->coors_range, d->max_points, d->max_voxels, d->voxels, s0.indices, 4, 0,
+                              d->num_points_per_voxel, d->mean, d->mean_features, d->mean_stride,
+                              d->counts_dev, s0.bound, overflow_dev, wss, d->vox_workspace_bytes, st, &vf);
     if (rc != SF_OK) return rc;
   }
   // ---- coordinate hash of the voxels; the same launch opens the first SubM table ---------------------

@@ -16,12 +16,13 @@ struct SfVoxFuse {
   int tables_ready;   // the slot table was filled by the caller
 };
 
-int sf_int_hard_voxelize(const float *points, int n, int f, const float voxel_size[3],
-                         const float coors_range[6], int max_points, int max_voxels, float *voxels,
-                         int *coors, int coors_stride, int batch_idx, int *num_points_per_voxel,
-                         float *mean, int mean_features, int mean_stride, int *row_count_dev,
-                         int rows_capacity, int *overflow_dev, int *voxel_num_host, void *workspace,
-                         size_t workspace_bytes, hipStream_t st, const SfVoxFuse *fuse);
+int sf_int_hard_voxelize(int count, const float *const *points, const int *n, int f,
+                         const float voxel_size[3], const float coors_range[6], int max_points,
+                         int max_voxels, float *voxels, int *coors, int coors_stride, int batch_idx0,
+                         int *num_points_per_voxel, float *mean, int mean_features, int mean_stride,
+                         int *row_count_dev, int rows_capacity, int *overflow_dev,
+                         void *const *workspaces, size_t workspace_bytes, hipStream_t st,
+                         const SfVoxFuse *fuse);
 // the slot table inside a voxelizer workspace (what a caller with tables_ready fills with
 // (EMPTY, INT_MAX) pairs): pointer and number of 32-bit words
 void sf_int_vox_table(void *workspace, int n, int max_points, uint32_t **table, size_t *words);

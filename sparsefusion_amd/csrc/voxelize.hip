@@ -70,7 +70,24 @@ __global__ void dynamic_voxelize_kernel(const float *__restrict__ points, int n,
   }
 }
 
-// misc words: [0] cut point index, [1] voxel_num of this call, [2] overflow, [3] base row
+// One sample of a launch: its points and its slice of the workspace.  Every kernel of the hard path
+// takes up to kVoxBatch samples (blockIdx.y picks one): the samples of a batch are independent but
+// for the base row of their voxels, and each of these kernels is latency bound at one frame's size,
+// so a batch costs little more than one sample (8 samples launched one after the other: 8 x).
+struct VoxSample {
+  const float *points;
+  uint32_t *kf, *sbound;
+  int *lists, *pslot, *bsum, *misc, *slot_vid;
+  int n, batch_idx, nblk;
+  uint32_t mask;
+};
+constexpr int kVoxBatch = 8;
+struct VoxBatch {
+  VoxSample s[kVoxBatch];
+};
+
+// misc words: [0] cut point index, [1] voxel_num of this sample, [2] overflow, [3] base row of the
+// sample's voxels, [4] row count in front of the launch's first sample
 // slot table: kf[2*slot] = key, kf[2*slot + 1] = smallest point index of the voxel; the bound words
 // (one per slot, unsigned: both fill values read as "no bound") follow the table and share its fill
 __global__ void vox_fill_kernel(uint2 *__restrict__ kf, long long n_slots, int *__restrict__ misc,
@@ -88,10 +105,14 @@ __global__ void vox_fill_kernel(uint2 *__restrict__ kf, long long n_slots, int *
   }
 }
 
-__global__ void vox_insert_kernel(const float *__restrict__ points, int n, int f, int max_points,
-                                  VoxParams vp, uint32_t *__restrict__ kf, uint32_t mask,
-                                  uint32_t *__restrict__ sbound, int *__restrict__ pslot,
+__global__ void vox_insert_kernel(VoxBatch vb, int f, int max_points, VoxParams vp,
                                   int *__restrict__ overflow_dev) {
+  const VoxSample &S = vb.s[blockIdx.y];
+  const float *__restrict__ points = S.points;
+  uint32_t *__restrict__ kf = S.kf, *__restrict__ sbound = S.sbound;
+  int *__restrict__ pslot = S.pslot;
+  const int n = S.n;
+  const uint32_t mask = S.mask;
   const int lane = threadIdx.x & 63;
   // (the loop bound is the same for the lanes of a wave: the run detection below shuffles)
   for (int base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
@@ -160,37 +181,59 @@ __device__ __forceinline__ bool is_first_point(int i, int n, const int *__restri
 constexpr int kBoundedBit = 1 << 30;
 
 __global__ void __launch_bounds__(kThreads)
-vox_count_kernel(int n, const int *__restrict__ pslot, const uint32_t *__restrict__ kf,
-                 int *__restrict__ bsum, int *__restrict__ misc,
-                 const int *__restrict__ row_count_dev) {
+vox_count_kernel(VoxBatch vb, const int *__restrict__ row_count_dev) {
   __shared__ int smem[17];
+  const VoxSample &S = vb.s[blockIdx.y];
+  if ((int)blockIdx.x >= S.nblk) return;
   if (blockIdx.x == 0 && threadIdx.x == 0) {   // read by vox_assign, the next launch
-    misc[0] = SF_INT_MAX;
-    misc[1] = 0;
-    misc[3] = row_count_dev ? *row_count_dev : 0;
+    S.misc[0] = SF_INT_MAX;
+    S.misc[1] = 0;
+    S.misc[4] = row_count_dev ? *row_count_dev : 0;
   }
   int base = blockIdx.x * kChunk + threadIdx.x * kItems;
   int c = 0;
 #pragma unroll
   for (int e = 0; e < kItems; ++e) {
     int slot;
-    c += is_first_point(base + e, n, pslot, kf, &slot) ? 1 : 0;
+    c += is_first_point(base + e, S.n, S.pslot, S.kf, &slot) ? 1 : 0;
   }
   int total = sf_block_sum(c, smem);
-  if (threadIdx.x == 0) bsum[blockIdx.x] = total;
+  if (threadIdx.x == 0) S.bsum[blockIdx.x] = total;
+}
+
+// voxels a sample contributes: its first points, cut at max_voxels, clipped to the rows left
+__device__ __forceinline__ int vox_rows_of(int all, int max_voxels, int base_row, int rows_capacity,
+                                           bool *clipped) {
+  int vnum = (max_voxels >= 0 && all > max_voxels) ? max_voxels : all;
+  *clipped = base_row + vnum > rows_capacity;
+  if (*clipped) vnum = rows_capacity > base_row ? rows_capacity - base_row : 0;
+  return vnum;
 }
 
 __global__ void __launch_bounds__(kThreads)
-vox_assign_kernel(int n, int max_points, int max_voxels, VoxParams vp, const int *__restrict__ pslot,
-                  const uint32_t *__restrict__ kf, const uint32_t *__restrict__ sbound,
-                  const int *__restrict__ bsum, int nblk,
-                  int *__restrict__ slot_vid, int *__restrict__ lists, int *__restrict__ coors,
-                  int coors_stride, int batch_idx, int rows_capacity, int *__restrict__ misc,
+vox_assign_kernel(VoxBatch vb, int count, int max_points, int max_voxels, VoxParams vp,
+                  int *__restrict__ coors, int coors_stride, int rows_capacity,
                   int *__restrict__ row_count_dev, int *__restrict__ overflow_dev) {
   __shared__ int smem[17];
+  const int sample = blockIdx.y;
+  const VoxSample &S = vb.s[sample];
+  if ((int)blockIdx.x >= S.nblk) return;
+  const int n = S.n;
+  const int *__restrict__ pslot = S.pslot;
+  const uint32_t *__restrict__ kf = S.kf;
+  int *__restrict__ misc = S.misc;
+  // base row: the samples in front of this one in the launch append first (same rule as a
+  // sequence of single-sample calls: cut at max_voxels, clipped to the rows that are left)
+  int base_row = misc[4];
+  for (int q = 0; q < sample; ++q) {
+    int pa = 0;
+    for (int i = threadIdx.x; i < vb.s[q].nblk; i += blockDim.x) pa += vb.s[q].bsum[i];
+    const int all_q = sf_block_sum(pa, smem);
+    bool clipped;
+    base_row += vox_rows_of(all_q, max_voxels, base_row, rows_capacity, &clipped);
+  }
   int before, all;
-  sf_block_prefix_of(bsum, nblk, blockIdx.x, smem, &before, &all);
-  const int base_row = misc[3];
+  sf_block_prefix_of(S.bsum, S.nblk, blockIdx.x, smem, &before, &all);
   int base = blockIdx.x * kChunk + threadIdx.x * kItems;
   int slots[kItems];
   unsigned flags = 0;
@@ -211,10 +254,10 @@ vox_assign_kernel(int n, int max_points, int max_voxels, VoxParams vp, const int
     if (max_voxels >= 0 && vid == max_voxels) misc[0] = base + e;  // the reference's `break`
     const bool keep = max_voxels < 0 || vid < max_voxels;
     // bit 30: the voxel has a bound (vox_collect then reads it; the fill values have bits 0-30 set)
-    const bool bounded = (sbound[slots[e]] & 0x7FFFFFFFu) != 0x7FFFFFFFu;
-    slot_vid[slots[e]] = keep ? (vid | (bounded ? kBoundedBit : 0)) : -1;
+    const bool bounded = (S.sbound[slots[e]] & 0x7FFFFFFFu) != 0x7FFFFFFFu;
+    S.slot_vid[slots[e]] = keep ? (vid | (bounded ? kBoundedBit : 0)) : -1;
     if (keep) {
-      int *list = lists + (size_t)vid * max_points;
+      int *list = S.lists + (size_t)vid * max_points;
       list[0] = base + e;   // the first point is the smallest index: it opens the list
       for (int s = 1; s < max_points; ++s) list[s] = SF_INT_MAX;
       int row = base_row + vid;
@@ -225,7 +268,7 @@ vox_assign_kernel(int n, int max_points, int max_voxels, VoxParams vp, const int
         uint32_t zy = key / gx;
         int y = (int)(zy % gy), z = (int)(zy / gy);
         int *o = coors + (size_t)row * coors_stride;
-        if (coors_stride == 4) *o++ = batch_idx;
+        if (coors_stride == 4) *o++ = S.batch_idx;
         o[0] = z;
         o[1] = y;
         o[2] = x;
@@ -236,13 +279,12 @@ vox_assign_kernel(int n, int max_points, int max_voxels, VoxParams vp, const int
     ++vid;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    int vnum = (max_voxels >= 0 && all > max_voxels) ? max_voxels : all;
-    if (base_row + vnum > rows_capacity) {
-      vnum = rows_capacity > base_row ? rows_capacity - base_row : 0;
-      if (overflow_dev) *overflow_dev = 1;
-    }
+    bool clipped;
+    const int vnum = vox_rows_of(all, max_voxels, base_row, rows_capacity, &clipped);
+    if (clipped && overflow_dev) *overflow_dev = 1;
     misc[1] = vnum;
-    if (row_count_dev) *row_count_dev = base_row + vnum;
+    misc[3] = base_row;
+    if (row_count_dev && sample == count - 1) *row_count_dev = base_row + vnum;
   }
 }
 
@@ -253,10 +295,13 @@ vox_assign_kernel(int n, int max_points, int max_voxels, VoxParams vp, const int
 // entries smaller than the point (entries only ever decrease, so a stale read can only start the
 // cascade too early, never too late).  MP == 0: any max_points, entry by entry.
 template <int MP>
-__global__ void vox_collect_kernel(int n, int max_points, const int *__restrict__ pslot,
-                                   const int *__restrict__ slot_vid, const uint32_t *__restrict__ sbound,
-                                   const int *__restrict__ misc, int *__restrict__ lists) {
-  const int cut = misc[0];
+__global__ void vox_collect_kernel(VoxBatch vb, int max_points) {
+  const VoxSample &S = vb.s[blockIdx.y];
+  const int n = S.n;
+  const int *__restrict__ pslot = S.pslot, *__restrict__ slot_vid = S.slot_vid;
+  const uint32_t *__restrict__ sbound = S.sbound;
+  int *__restrict__ lists = S.lists;
+  const int cut = S.misc[0];
   const int stop = cut < n ? cut : n;   // points from the cut on belong to no voxel
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < stop; i += gridDim.x * blockDim.x) {
     const int slot = pslot[i];
@@ -297,10 +342,11 @@ __global__ void vox_collect_kernel(int n, int max_points, const int *__restrict_
   }
 }
 
-__global__ void vox_write_kernel(const float *__restrict__ points, int f, int max_points,
-                                 const int *__restrict__ lists, const int *__restrict__ misc,
-                                 float *__restrict__ voxels) {
-  const int vnum = misc[1], base_row = misc[3];
+__global__ void vox_write_kernel(VoxBatch vb, int f, int max_points, float *__restrict__ voxels) {
+  const VoxSample &S = vb.s[blockIdx.y];
+  const float *__restrict__ points = S.points;
+  const int *__restrict__ lists = S.lists;
+  const int vnum = S.misc[1], base_row = S.misc[3];
   const long long total = (long long)vnum * max_points * f;
   const int per_voxel = max_points * f;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
@@ -316,11 +362,12 @@ __global__ void vox_write_kernel(const float *__restrict__ points, int f, int ma
 
 // num_points_per_voxel (voxelization_cpu.cpp:89-95) + HardSimpleVFE mean (voxel_encoder.py:42-44:
 // sum over the slots in order, zeros included, divided by the count).
-__global__ void vox_reduce_kernel(const float *__restrict__ points, int f, int max_points,
-                                  const int *__restrict__ lists, const int *__restrict__ misc,
-                                  int *__restrict__ npv, float *__restrict__ mean, int mean_features,
-                                  int mean_stride) {
-  const int vnum = misc[1], base_row = misc[3];
+__global__ void vox_reduce_kernel(VoxBatch vb, int f, int max_points, int *__restrict__ npv,
+                                  float *__restrict__ mean, int mean_features, int mean_stride) {
+  const VoxSample &S = vb.s[blockIdx.y];
+  const float *__restrict__ points = S.points;
+  const int *__restrict__ lists = S.lists;
+  const int vnum = S.misc[1], base_row = S.misc[3];
   const int cols = mean ? mean_stride : 1;
   const long long total = (long long)vnum * cols;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
@@ -345,11 +392,13 @@ __global__ void vox_reduce_kernel(const float *__restrict__ points, int f, int m
 // stride)), reads the voxel's list once, copies its column of every listed point and sums it in
 // slot order as it goes (the mean adds the same values in the same order as vox_reduce_kernel).
 template <int MP>
-__global__ void vox_write_reduce_kernel(const float *__restrict__ points, int f, int max_points,
-                                        const int *__restrict__ lists, const int *__restrict__ misc,
-                                        float *__restrict__ voxels, int *__restrict__ npv,
-                                        float *__restrict__ mean, int mean_features, int mean_stride) {
-  const int vnum = misc[1], base_row = misc[3];
+__global__ void vox_write_reduce_kernel(VoxBatch vb, int f, float *__restrict__ voxels,
+                                        int *__restrict__ npv, float *__restrict__ mean,
+                                        int mean_features, int mean_stride) {
+  const VoxSample &S = vb.s[blockIdx.y];
+  const float *__restrict__ points = S.points;
+  const int *__restrict__ lists = S.lists;
+  const int vnum = S.misc[1], base_row = S.misc[3];
   const int cols = (mean && mean_stride > f) ? mean_stride : f;
   const long long total = (long long)vnum * cols;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
@@ -485,89 +534,110 @@ extern "C" size_t sf_hard_voxelize_workspace(int n, int max_points) {
 
 namespace {
 
-// Body of both hard-voxelize entry points; `workspace` is device memory of at least
-// carve(nullptr, n, max_points).bytes bytes, whoever owns it.
-int hard_voxelize_impl(const float *points, int n, int f, const float voxel_size[3],
-                       const float coors_range[6], int max_points, int max_voxels, float *voxels,
-                       int *coors, int coors_stride, int batch_idx, int *num_points_per_voxel,
-                       float *mean, int mean_features, int mean_stride, int *row_count_dev,
-                       int rows_capacity, int *overflow_dev, int *voxel_num_host, void *workspace,
-                       size_t workspace_bytes, hipStream_t st, const SfVoxFuse *fuse = nullptr) {
-
-  SF_CHECK_ARG(n >= 0 && n < (1 << 30) && f >= 3, "bad shape n=%d f=%d (need f >= 3, n < 2^30)", n, f);
+// Body of every hard-voxelize entry point: `count` samples whose voxels are appended in order
+// (sample q of the call gets batch index batch_idx0 + q); workspaces[q] is device memory of at least
+// carve(nullptr, n[q], max_points).bytes bytes, whoever owns it.  The samples go through the
+// kernels kVoxBatch at a time.
+int hard_voxelize_impl(int count, const float *const *points, const int *n, int f,
+                       const float voxel_size[3], const float coors_range[6], int max_points,
+                       int max_voxels, float *voxels, int *coors, int coors_stride, int batch_idx0,
+                       int *num_points_per_voxel, float *mean, int mean_features, int mean_stride,
+                       int *row_count_dev, int rows_capacity, int *overflow_dev, int *voxel_num_host,
+                       void *const *workspaces, size_t workspace_bytes, hipStream_t st,
+                       const SfVoxFuse *fuse = nullptr) {
+  SF_CHECK_ARG(count >= 1 && points && n && workspaces, "bad sample list");
+  SF_CHECK_ARG(f >= 3, "bad point width f=%d (need f >= 3)", f);
   SF_CHECK_ARG(max_points >= 1, "max_points=%d: the hard path needs max_points >= 1 "
                "(use sf_dynamic_voxelize for -1)", max_points);
   SF_CHECK_ARG(max_voxels >= -1, "max_voxels=%d", max_voxels);
   SF_CHECK_ARG(rows_capacity >= 0, "rows_capacity=%d", rows_capacity);
   SF_CHECK_ARG((coors || rows_capacity == 0) && (coors_stride == 3 || coors_stride == 4),
                "coors NULL or stride %d", coors_stride);
+  SF_CHECK_ARG(count == 1 || row_count_dev, "several samples append through row_count_dev");
   if (mean)
     SF_CHECK_ARG(mean_features >= 1 && mean_features <= f && mean_stride >= mean_features,
                  "mean_features=%d mean_stride=%d f=%d", mean_features, mean_stride, f);
   VoxParams vp;
   int rc = make_params(voxel_size, coors_range, &vp);
   if (rc != SF_OK) return rc;
-  VoxWorkspace w = carve(workspace, n, max_points);
-  if (!workspace || workspace_bytes < w.bytes) {
-    sf_set_error("workspace too small: %zu < %zu bytes", workspace_bytes, w.bytes);
-    return SF_ERR_WORKSPACE;
+  for (int q = 0; q < count; ++q) {
+    SF_CHECK_ARG(n[q] >= 0 && n[q] < (1 << 30), "sample %d: n=%d (need 0 <= n < 2^30)", q, n[q]);
+    const size_t need = carve(nullptr, n[q], max_points).bytes;
+    if (!workspaces[q] || workspace_bytes < need) {
+      sf_set_error("workspace too small: %zu < %zu bytes", workspace_bytes, need);
+      return SF_ERR_WORKSPACE;
+    }
+    SF_CHECK_ARG(n[q] == 0 || points[q], "points is NULL");
   }
-  SF_CHECK_ARG(n == 0 || points, "points is NULL");
-
-  if (!(fuse && fuse->tables_ready && n > 0)) {
-    // table + bound words: 3 * cap words = (cap + cap / 2) slots' worth of fill
-    hipLaunchKernelGGL(vox_fill_kernel, dim3(sf_grid(3 * w.cap / 4, kThreads)), dim3(kThreads), 0, st,
-                       reinterpret_cast<uint2 *>(w.kf), w.cap + w.cap / 2, w.misc, (const int *)row_count_dev);
+  const bool fused_wr = voxels && (num_points_per_voxel || mean) && (max_points == 10 || max_points == 5);
+  VoxWorkspace w_last = carve(workspaces[count - 1], n[count - 1], max_points);
+  for (int q0 = 0; q0 < count; q0 += kVoxBatch) {
+    VoxBatch vb = {};
+    int nb = 0, n_max = 0, nblk_max = 0;
+    for (int q = q0; q < count && q < q0 + kVoxBatch; ++q) {
+      VoxWorkspace w = carve(workspaces[q], n[q], max_points);
+      if (!(fuse && fuse->tables_ready && n[q] > 0)) {
+        // table + bound words: 3 * cap words = (cap + cap / 2) slots' worth of fill
+        hipLaunchKernelGGL(vox_fill_kernel, dim3(sf_grid(3 * w.cap / 4, kThreads)), dim3(kThreads), 0, st,
+                           reinterpret_cast<uint2 *>(w.kf), w.cap + w.cap / 2, w.misc,
+                           (const int *)row_count_dev);
+        SF_CHECK_LAUNCH();
+      }
+      if (n[q] == 0) continue;   // an empty sample appends nothing
+      VoxSample &S = vb.s[nb++];
+      S.points = points[q];
+      S.kf = w.kf;
+      S.sbound = w.sbound;
+      S.lists = w.lists;
+      S.pslot = w.pslot;
+      S.bsum = w.bsum;
+      S.misc = w.misc;
+      S.slot_vid = w.slot_vid;
+      S.n = n[q];
+      S.batch_idx = batch_idx0 + q;
+      S.nblk = w.nblk;
+      S.mask = (uint32_t)(w.cap - 1);
+      if (n[q] > n_max) n_max = n[q];
+      if (w.nblk > nblk_max) nblk_max = w.nblk;
+    }
+    if (nb == 0) continue;
+    const dim3 blk(kThreads);
+    hipLaunchKernelGGL(vox_insert_kernel, dim3(sf_grid(n_max, kThreads), nb), blk, 0, st, vb, f, max_points,
+                       vp, overflow_dev);
     SF_CHECK_LAUNCH();
-  }
-  if (n > 0) {
-    hipLaunchKernelGGL(vox_insert_kernel, dim3(sf_grid(n, kThreads)), dim3(kThreads), 0, st, points,
-                       n, f, max_points, vp, w.kf, (uint32_t)(w.cap - 1), w.sbound, w.pslot, overflow_dev);
+    hipLaunchKernelGGL(vox_count_kernel, dim3(nblk_max, nb), blk, 0, st, vb, (const int *)row_count_dev);
     SF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(vox_count_kernel, dim3(w.nblk), dim3(kThreads), 0, st, n,
-                       (const int *)w.pslot, (const uint32_t *)w.kf, w.bsum, w.misc,
-                       (const int *)row_count_dev);
-    SF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(vox_assign_kernel, dim3(w.nblk), dim3(kThreads), 0, st, n, max_points,
-                       max_voxels, vp, (const int *)w.pslot, (const uint32_t *)w.kf,
-                       (const uint32_t *)w.sbound, (const int *)w.bsum, w.nblk, w.slot_vid, w.lists, coors, coors_stride,
-                       batch_idx, rows_capacity, w.misc, row_count_dev, overflow_dev);
+    hipLaunchKernelGGL(vox_assign_kernel, dim3(nblk_max, nb), blk, 0, st, vb, nb, max_points, max_voxels, vp,
+                       coors, coors_stride, rows_capacity, row_count_dev, overflow_dev);
     SF_CHECK_LAUNCH();
     auto collect = max_points == 10 ? vox_collect_kernel<10>
                    : max_points == 5 ? vox_collect_kernel<5>
-                   : max_points <= 4 ? vox_collect_kernel<0> : vox_collect_kernel<0>;
-    if (max_points == 20) collect = vox_collect_kernel<20>;
-    if (max_points == 32) collect = vox_collect_kernel<32>;
-    hipLaunchKernelGGL(collect, dim3(sf_grid(n, kThreads)), dim3(kThreads), 0, st, n, max_points,
-                       (const int *)w.pslot, (const int *)w.slot_vid, (const uint32_t *)w.sbound,
-                       (const int *)w.misc, w.lists);
+                   : max_points == 20 ? vox_collect_kernel<20>
+                   : max_points == 32 ? vox_collect_kernel<32> : vox_collect_kernel<0>;
+    hipLaunchKernelGGL(collect, dim3(sf_grid(n_max, kThreads), nb), blk, 0, st, vb, max_points);
     SF_CHECK_LAUNCH();
-    long long bound_v = (max_voxels >= 0 && max_voxels < n) ? max_voxels : n;
-    const bool fused_wr = voxels && (num_points_per_voxel || mean) && (max_points == 10 || max_points == 5);
+    const long long bound_v = (max_voxels >= 0 && max_voxels < n_max) ? max_voxels : n_max;
     if (fused_wr) {
       const long long cols = (mean && mean_stride > f) ? mean_stride : f;
       auto kern = max_points == 10 ? vox_write_reduce_kernel<10> : vox_write_reduce_kernel<5>;
-      hipLaunchKernelGGL(kern, dim3(sf_grid(bound_v * cols, kThreads)), dim3(kThreads), 0, st, points, f,
-                         max_points, (const int *)w.lists, (const int *)w.misc, voxels,
+      hipLaunchKernelGGL(kern, dim3(sf_grid(bound_v * cols, kThreads), nb), blk, 0, st, vb, f, voxels,
                          num_points_per_voxel, mean, mean_features, mean_stride);
       SF_CHECK_LAUNCH();
     }
     if (voxels && !fused_wr) {
-      hipLaunchKernelGGL(vox_write_kernel, dim3(sf_grid(bound_v * max_points * f, kThreads)),
-                         dim3(kThreads), 0, st, points, f, max_points, (const int *)w.lists,
-                         (const int *)w.misc, voxels);
+      hipLaunchKernelGGL(vox_write_kernel, dim3(sf_grid(bound_v * max_points * f, kThreads), nb), blk, 0, st,
+                         vb, f, max_points, voxels);
       SF_CHECK_LAUNCH();
     }
     if ((num_points_per_voxel || mean) && !fused_wr) {
-      long long cols = mean ? mean_stride : 1;
-      hipLaunchKernelGGL(vox_reduce_kernel, dim3(sf_grid(bound_v * cols, kThreads)), dim3(kThreads),
-                         0, st, points, f, max_points, (const int *)w.lists, (const int *)w.misc,
-                         num_points_per_voxel, mean, mean_features, mean_stride);
+      const long long cols = mean ? mean_stride : 1;
+      hipLaunchKernelGGL(vox_reduce_kernel, dim3(sf_grid(bound_v * cols, kThreads), nb), blk, 0, st, vb, f,
+                         max_points, num_points_per_voxel, mean, mean_features, mean_stride);
       SF_CHECK_LAUNCH();
     }
   }
-  if (voxel_num_host) {
-    SF_CHECK_HIP(hipMemcpyAsync(voxel_num_host, w.misc + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+  if (voxel_num_host) {   // (single-sample entry points only)
+    SF_CHECK_HIP(hipMemcpyAsync(voxel_num_host, w_last.misc + 1, sizeof(int), hipMemcpyDeviceToHost, st));
     SF_CHECK_HIP(hipStreamSynchronize(st));
   }
   return SF_OK;
@@ -604,16 +674,17 @@ int static_scratch(void **ptr) {
 
 }  // namespace
 
-int sf_int_hard_voxelize(const float *points, int n, int f, const float voxel_size[3],
-                         const float coors_range[6], int max_points, int max_voxels, float *voxels,
-                         int *coors, int coors_stride, int batch_idx, int *num_points_per_voxel,
-                         float *mean, int mean_features, int mean_stride, int *row_count_dev,
-                         int rows_capacity, int *overflow_dev, int *voxel_num_host, void *workspace,
-                         size_t workspace_bytes, hipStream_t st, const SfVoxFuse *fuse) {
-  return hard_voxelize_impl(points, n, f, voxel_size, coors_range, max_points, max_voxels, voxels,
-                            coors, coors_stride, batch_idx, num_points_per_voxel, mean,
+int sf_int_hard_voxelize(int count, const float *const *points, const int *n, int f,
+                         const float voxel_size[3], const float coors_range[6], int max_points,
+                         int max_voxels, float *voxels, int *coors, int coors_stride, int batch_idx0,
+                         int *num_points_per_voxel, float *mean, int mean_features, int mean_stride,
+                         int *row_count_dev, int rows_capacity, int *overflow_dev,
+                         void *const *workspaces, size_t workspace_bytes, hipStream_t st,
+                         const SfVoxFuse *fuse) {
+  return hard_voxelize_impl(count, points, n, f, voxel_size, coors_range, max_points, max_voxels, voxels,
+                            coors, coors_stride, batch_idx0, num_points_per_voxel, mean,
                             mean_features, mean_stride, row_count_dev, rows_capacity, overflow_dev,
-                            voxel_num_host, workspace, workspace_bytes, st, fuse);
+                            nullptr, workspaces, workspace_bytes, st, fuse);
 }
 
 void sf_int_vox_table(void *workspace, int n, int max_points, uint32_t **table, size_t *words) {
@@ -629,10 +700,11 @@ extern "C" int sf_hard_voxelize(const float *points, int n, int f, const float v
                                 int mean_stride, int *row_count_dev, int rows_capacity,
                                 int *overflow_dev, int *voxel_num_host, void *workspace,
                                 size_t workspace_bytes, void *stream) {
-  return hard_voxelize_impl(points, n, f, voxel_size, coors_range, max_points, max_voxels, voxels,
+  SF_CHECK_ARG(n >= 0, "bad shape n=%d", n);
+  return hard_voxelize_impl(1, &points, &n, f, voxel_size, coors_range, max_points, max_voxels, voxels,
                             coors, coors_stride, batch_idx, num_points_per_voxel, mean,
                             mean_features, mean_stride, row_count_dev, rows_capacity, overflow_dev,
-                            voxel_num_host, workspace, workspace_bytes, (hipStream_t)stream);
+                            voxel_num_host, &workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int sf_hard_voxelize_static(const float *points, int n, int f,
@@ -655,10 +727,10 @@ extern "C" int sf_hard_voxelize_static(const float *points, int n, int f,
   if (rc != SF_OK) return rc;
   // every word the kernels read is (re)initialised by vox_fill / written earlier in the same call,
   // so the previous call's contents never leak into this one
-  return hard_voxelize_impl(points, n, f, voxel_size, coors_range, max_points, max_voxels, voxels,
+  return hard_voxelize_impl(1, &points, &n, f, voxel_size, coors_range, max_points, max_voxels, voxels,
                             coors, coors_stride, batch_idx, num_points_per_voxel, mean,
                             mean_features, mean_stride, row_count_dev, rows_capacity, overflow_dev,
-                            nullptr, ws, kStaticScratchBytes, (hipStream_t)stream);
+                            nullptr, &ws, kStaticScratchBytes, (hipStream_t)stream);
 }
 
 extern "C" int sf_voxel_mean(const float *voxels, const int *num_points_per_voxel, const int *m_dev,
