@@ -34,7 +34,8 @@ class Walker:
     """Assigns a dispatch to a stage from its kernel name and the dispatches before it."""
 
     def __init__(self, conv_rows):
-        self.conv_rows = conv_rows      # kernel name -> row label
+        self.conv_rows = conv_rows      # kernel name -> row labels of its launches, in frame order
+        self.seen = collections.Counter()
         self.strided = 0
         self.plan = 0
         self.frames = 0
@@ -67,7 +68,12 @@ class Walker:
                     'dense_scatter_kernel'):
             return 'dense'
         if k in self.conv_rows:
-            return self.conv_rows[k]
+            # two groups can share an instantiation (bf16: the SubM layers of the last stage and
+            # conv_out): the i-th launch of a kernel in a frame belongs to the i-th layer that uses it
+            labs = self.conv_rows[k]
+            lab = labs[self.seen[k] % len(labs)]
+            self.seen[k] += 1
+            return lab
         if base == 'cast_bf16_kernel':
             return 'cast'
         return None
@@ -102,9 +108,11 @@ def main():
 
     conv_rows, conv_launch = {}, {}
     for g, v in d['groups'].items():
-        for k in v['kernels']:
-            conv_rows[k] = 'conv ' + g
         conv_launch['conv ' + g] = v['launches']
+    for lay in d['layers']:
+        g = f"{lay['cin']}x{lay['cout']}" + ('b' if lay['bf16'] else '') + \
+            ('' if lay['K'] == 27 else f"k{lay['K']}") + ('' if lay['subm'] else 's')
+        conv_rows.setdefault(lay['kernel'], []).append('conv ' + g)
 
     tr = list(csv.DictReader(open(args.trace)))
     tr.sort(key=lambda r: int(r['Start_Timestamp']))
