@@ -24,6 +24,7 @@ from sparsefusion_amd import _lib, synth  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--frame', type=int, default=0)
+    ap.add_argument('--grid-cap', type=int, default=0, help='limit the persistent grid (sf_debug_ordered_grid_cap)')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     pts = synth.nuscenes_frame(args.frame)
@@ -32,6 +33,8 @@ def main():
     L = _lib.lib()
     raw = ctypes.CDLL(_lib.LIB_PATH)
     raw.sf_debug_dma_wg_times.argtypes = [ctypes.c_void_p]
+    if args.grid_cap:
+        raw.sf_debug_ordered_grid_cap(args.grid_cap)
     buf = torch.zeros(2 * 4096, dtype=torch.int64, device=dev)
     with torch.no_grad():
         for _ in range(3):
