@@ -369,8 +369,11 @@ SF_API int sf_row_order_size(int n_bound);
  *   [n_bound, +T)           the tile schedule: the 64-row tiles of the sorted rows by descending cost
  *                           ((16-row block, offset) products + 3 per active offset), dealt to the
  *                           persistent workgroups of the convolution
- *   + 32 T                  tile headers: [0] active offsets, [1..27] k | block mask << 8 ascending,
- *                           [28] cost, [29] mask of the active offsets
+ *   + 32 T                  tile headers: [0] phases np = max(active offsets, 3), [1..np] the phases
+ *                           ready made in execution order -- the offset k_first (the centre of a
+ *                           SubM rulebook; -1: none) first when active, then ascending, then
+ *                           padding: k | block mask << 5 | flags << 9 --, [28] cost, [29] mask of
+ *                           the active offsets
  *   + 27 * 64 T             the neighbour table permuted into the sorted order, column per offset
  * The buffer holds sf_row_order_size(n_bound) ints.  The sort is a hand-written 3-pass radix sort
  * bounded by the device-side row count (no library call, no host synchronisation); seven short
@@ -378,8 +381,8 @@ SF_API int sf_row_order_size(int n_bound);
  * No reference counterpart: the reference's rulebook has no row order of its own (pairs are
  * listed per offset, spconv_ops.h:55-59); this is the schedule sf_sparse_conv_f32_ordered runs
  * its tiles in, built once per rulebook and shared by every layer that uses it. */
-SF_API int sf_row_order_by_mask(const int *nbr, int nbr_stride, int K, const int *n_dev, int n_bound,
-                                int *row_order, void *workspace, size_t workspace_bytes,
+SF_API int sf_row_order_by_mask(const int *nbr, int nbr_stride, int K, int k_first, const int *n_dev,
+                                int n_bound, int *row_order, void *workspace, size_t workspace_bytes,
                                 void *stream);
 
 /* sf_sparse_conv_f32 (same reference interface: indice_conv_fp32 / indice_subm_conv,
@@ -389,7 +392,8 @@ SF_API int sf_row_order_by_mask(const int *nbr, int nbr_stride, int K, const int
  * the MFMA accumulators, (offset, 16-row block) products without a partner skipped.  The kernel
  * reads the plan's permuted table; nbr / nbr_stride are only validated.
  * Results are fp32 FMA chains in the reference's order (centre offset first for SubM, then
- * offsets ascending), independent of row_order.  features_in is (n_in_bound, cin_padded) f32
+ * offsets ascending), independent of row_order; the order is part of the plan (k_first of
+ * sf_row_order_by_mask), k_first here must be the same value.  features_in is (n_in_bound, cin_padded) f32
  * with cin_padded in {16, 32, 64, 128}: n_in_bound rows must be addressable (the gather is bounds
  * checked against it; table < 4 GiB). */
 SF_API int sf_sparse_conv_f32_ordered(const float *features_in, int n_in_bound, int cin_padded,

@@ -79,7 +79,7 @@ SIGNATURES = {
     'sf_last_conv_kernel': (C.c_char_p, []),
     'sf_row_order_workspace': (_sz, [_i]),
     'sf_row_order_size': (_i, [_i]),
-    'sf_row_order_by_mask': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _sz, _vp]),
+    'sf_row_order_by_mask': (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _sz, _vp]),
     'sf_sparse_conv_f32_ordered': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i,
                                         _vp, _vp, _i, _vp]),
     'sf_conv_padded_cin_bf16': (_i, [_i]),

@@ -170,7 +170,8 @@ extern "C" int sf_lidar_front(const SfFrontDesc *d, void *stream) {
     const SfRulebook &r = d->rulebooks[i];
     if (!r.plan) return SF_OK;
     int K = r.ksize[0] * r.ksize[1] * r.ksize[2];
-    return sf_int_row_order(r.nbr, r.nbr_stride, K, d->counts_dev + r.dst, d->sets[r.dst].bound, r.plan,
+    return sf_int_row_order(r.nbr, r.nbr_stride, K, r.subm ? (K - 1) / 2 : -1, d->counts_dev + r.dst,
+                            d->sets[r.dst].bound, r.plan,
                             r.plan_ws, r.plan_ws_bytes, 1, st);
   };
   for (int i = 0; i < d->n_rulebooks; ++i) {

@@ -57,7 +57,7 @@ int sf_int_subm27(const int *outids, const int *n_dev, int n_bound, int batch, c
 int sf_int_scatter(const SfScatterJob *job, hipStream_t st);
 
 // sf_row_order_by_mask with the histogram tables zeroed by the caller
-int sf_int_row_order(const int *nbr, int nbr_stride, int K, const int *n_dev, int n_bound,
+int sf_int_row_order(const int *nbr, int nbr_stride, int K, int k_first, const int *n_dev, int n_bound,
                      int *row_order, void *workspace, size_t workspace_bytes, int hist_ready,
                      hipStream_t st);
 void sf_int_row_order_hist(void *workspace, int n_bound, uint32_t **hist, size_t *words);

@@ -58,8 +58,11 @@ struct ATileF {
 // Built once per rulebook (sf_row_order_by_mask), read by every layer that uses the rulebook:
 //   plan[0, n_bound)                 row_order: output rows by ascending 27-bit neighbour mask (stable)
 //   plan[n_bound, +T)                tile schedule: tiles by descending work (T = ceil(n_bound / 64))
-//   + T x 32 ints                    tile headers: [0] number of active offsets, [1..27] the active
-//                                    offsets ascending as k | (16-row block mask << 8), [28] work,
+//   + T x 32 ints                    tile headers: [0] number of phases np = max(active offsets, 3),
+//                                    [1..np] the phases READY MADE in execution order (the centre
+//                                    offset k_first first when active, then ascending):
+//                                    k | 16-row block mask << 5 | flags << 9 (1 multiplies, 2 first,
+//                                    4 last, 8 second phase of the tile, 16 valid), [28] work,
 //                                    [29] 27-bit mask of the active offsets
 //   + 27 x (64 T) ints               the neighbour table permuted into row_order (column per offset):
 //                                    a tile reads 256 contiguous bytes per offset
@@ -74,6 +77,7 @@ constexpr int kSortChunk = 2048;   // keys per 256-thread block: 4 waves x 8 bat
 constexpr int kSortBins = 512;     // 9-bit digits
 constexpr int kTileRows = 64;      // rows per tile of the ordered kernels
 constexpr int kHdrInts = 32;
+constexpr int kPlanMinPhases = 3;   // tiles are padded to this many phases (the kernels look that far ahead)
 
 // zeroes the histogram rows of the chunks in use (the tables are sized for the bound)
 __global__ void __launch_bounds__(256)
@@ -219,8 +223,9 @@ sort_scatter_kernel(const unsigned *__restrict__ keys, const int *__restrict__ r
 // One wave per tile of 64 sorted rows: permuted neighbour table, active offsets with their 16-row
 // block masks, work of the tile (number of (offset, block) products).
 __global__ void __launch_bounds__(256)
-tile_plan_kernel(const int *__restrict__ nbr, int nbr_stride, int K, const int *n_dev, int n_bound,
-                 int *__restrict__ order, int *__restrict__ hdr, int *__restrict__ nbrs, int s_stride) {
+tile_plan_kernel(const int *__restrict__ nbr, int nbr_stride, int K, int k_first, const int *n_dev,
+                 int n_bound, int *__restrict__ order, int *__restrict__ hdr, int *__restrict__ nbrs,
+                 int s_stride) {
   const int n = load_n(n_dev, n_bound);
   const int tiles = (n + kTileRows - 1) / kTileRows;
   const int lane = threadIdx.x & 63;
@@ -242,20 +247,35 @@ tile_plan_kernel(const int *__restrict__ nbr, int nbr_stride, int K, const int *
       for (int b = 0; b < 4; ++b) bm |= (int)(((bal >> (16 * b)) & 0xFFFFull) != 0) << b;
       if (lane == k) mybm = bm;
     }
-    const unsigned long long act = __ballot(mybm != 0);
-    const int pos = __popcll(act & ((1ull << lane) - 1ull));
+    // lane k < 27 holds the block mask of offset k.  Phases in execution order: the centre offset
+    // first (when it is active), then the active offsets ascending, then padding up to
+    // kPlanMinPhases (the reference's summation order, spconv_ops.h:300-356).
+    const unsigned act = (unsigned)__ballot(mybm != 0);
+    const int nact = __popc(act);
+    const int np = nact > kPlanMinPhases ? nact : kPlanMinPhases;
+    const bool centre = k_first >= 0 && k_first < K && ((act >> k_first) & 1u);
+    const int pc = centre ? __popc(act & ((1u << k_first) - 1u)) : -1;   // ascending rank of the centre
     int *h = hdr + (size_t)t * kHdrInts;
-    if (mybm != 0) h[1 + pos] = lane | (mybm << 8);
+    int pos = -1, word = 0;
+    if (lane < 32 && mybm != 0) {                 // an active offset: its phase
+      const int rank = __popc(act & ((1u << lane) - 1u));
+      pos = !centre ? rank : (lane == k_first ? 0 : (rank < pc ? rank + 1 : rank));
+      word = lane | (mybm << 5) | (1 << 9);
+    } else if (lane >= 32 && lane - 32 >= nact && lane - 32 < np) {   // a padding phase
+      pos = lane - 32;
+    }
+    if (pos >= 0)
+      h[1 + pos] = word | (((pos == 0 ? 2 : 0) | (pos == np - 1 ? 4 : 0) | (pos == 1 ? 8 : 0) | 16) << 9);
     int w = __popc(mybm);
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) w += __shfl_xor(w, d, 64);
     if (lane == 0) {
-      h[0] = __popcll(act);
+      h[0] = np;
       // cost of the tile for the schedule: a phase costs about three block products of fixed work
       // (descriptor, loads, barrier) besides its products; balancing products alone left the
       // workgroups up to 1.5x apart in phases (tools: LPT simulation on the frame's real masks)
-      h[28] = w + 3 * __popcll(act);
-      h[29] = (int)(unsigned)act;
+      h[28] = w + 3 * nact;
+      h[29] = (int)act;
     }
   }
 }
@@ -317,7 +337,7 @@ conv_f32_ordered_kernel(const float *__restrict__ feat, unsigned feat_bytes, Pla
   constexpr int NB = COUT / 16, NBW = NB / CG, RG = WAVES / CG, MBT = TM / 16, MBW = MBT / RG;
   constexpr int ITEMS = TM * CH, GI = ITEMS / NT;
   constexpr int kRun = 128;   // tiles per pipeline run
-  constexpr int kLook = 3;    // look-ahead in phases = least phases per tile (shorter tiles are padded)
+  // (look-ahead in phases = kPlanMinPhases, the least phases per tile: the plan pads shorter tiles)
   static_assert(NB % CG == 0 && WAVES % CG == 0 && MBT % RG == 0 && CIN % 16 == 0 && ITEMS % NT == 0,
                 "tile shape");
 
@@ -333,7 +353,7 @@ conv_f32_ordered_kernel(const float *__restrict__ feat, unsigned feat_bytes, Pla
   const int n_out = load_n(n_out_dev, n_out_bound);
   const __amdgpu_buffer_rsrc_t rs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(feat), 0, feat_bytes, 0x00020000);
-  const int kf = (k_first >= 0 && k_first < K) ? k_first : -1;
+  (void)k_first;   // the summation order (centre first) is part of the plan: sf_row_order_by_mask
   const int tiles = (n_out + TM - 1) / TM;
   const int G = gridDim.x, b = blockIdx.x;
   // snake deal: round i gives this workgroup schedule entry i*G + b (even i) or i*G + G-1-b (odd i)
@@ -381,19 +401,10 @@ conv_f32_ordered_kernel(const float *__restrict__ feat, unsigned feat_bytes, Pla
       d_tile = 0;
       d_info = 0;
       if (gj < cnt) {
-        const int nact = __builtin_amdgcn_readlane(hcur, 0), np = nact > kLook ? nact : kLook;
-        int li = ga;           // list index: the centre offset first, then ascending
-        if (kf >= 0) {
-          const unsigned am = (unsigned)__builtin_amdgcn_readlane(hcur, 29);
-          if ((am >> kf) & 1u) {
-            const int pc = __popc(am & ((1u << kf) - 1u));
-            li = ga == 0 ? pc : (ga <= pc ? ga - 1 : ga);
-          }
-        }
-        const int e = ga < nact ? __builtin_amdgcn_readlane(hcur, 1 + (li < 27 ? li : 0)) : 0;
+        // the plan holds the tile's phases ready made, in execution order (tile_plan_kernel)
+        const int np = __builtin_amdgcn_readlane(hcur, 0);
         d_tile = g_tile;
-        d_info = (e & 31) | (((e >> 8) & 15) << 5) |
-                 (((ga < nact ? 1 : 0) | (ga == 0 ? 2 : 0) | (ga == np - 1 ? 4 : 0) | (ga == 1 ? 8 : 0) | 16) << 9);
+        d_info = __builtin_amdgcn_readlane(hcur, 1 + ga);
         if (++ga == np) {
           ++gj;
           ga = 0;
@@ -618,7 +629,7 @@ conv_f32_dma_kernel(const float *__restrict__ feat, unsigned feat_bytes, PlanVie
   constexpr int RPI = 1024 / ROWB;             // rows one DMA instruction covers
   constexpr int IPW = TM / RPI / WAVES;        // DMA instructions per wave and phase
   constexpr int NBL = NBW * T;                 // filter loads per wave and phase
-  constexpr int kRun = 128, kLook = 3;
+  constexpr int kRun = 128;
   // memory operations a wave issues AFTER the DMA of phase q+1 (issued in phase q-1) until the end
   // of phase q: last phase's filters (loaded behind its multiply), this phase's indices, DMA, filters
   constexpr int kWaitN = 2 * IPW + 2 * NBL;
@@ -638,7 +649,7 @@ conv_f32_dma_kernel(const float *__restrict__ feat, unsigned feat_bytes, PlanVie
   const int n_out = load_n(n_out_dev, n_out_bound);
   const __amdgpu_buffer_rsrc_t rs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(feat), 0, feat_bytes, 0x00020000);
-  const int kf = (k_first >= 0 && k_first < K) ? k_first : -1;
+  (void)k_first;   // the summation order (centre first) is part of the plan: sf_row_order_by_mask
   const int tiles = (n_out + TM - 1) / TM;
   const int G = gridDim.x, b = blockIdx.x;
   const int full = tiles / G, rem = tiles - full * G;
@@ -695,19 +706,10 @@ conv_f32_dma_kernel(const float *__restrict__ feat, unsigned feat_bytes, PlanVie
       d_tile = 0;
       d_info = 0;
       if (gj < cnt) {
-        const int nact = __builtin_amdgcn_readlane(hcur, 0), np = nact > kLook ? nact : kLook;
-        int li = ga;
-        if (kf >= 0) {
-          const unsigned am = (unsigned)__builtin_amdgcn_readlane(hcur, 29);
-          if ((am >> kf) & 1u) {
-            const int pc = __popc(am & ((1u << kf) - 1u));
-            li = ga == 0 ? pc : (ga <= pc ? ga - 1 : ga);
-          }
-        }
-        const int e = ga < nact ? __builtin_amdgcn_readlane(hcur, 1 + (li < 27 ? li : 0)) : 0;
+        // the plan holds the tile's phases ready made, in execution order (tile_plan_kernel)
+        const int np = __builtin_amdgcn_readlane(hcur, 0);
         d_tile = g_tile;
-        d_info = (e & 31) | (((e >> 8) & 15) << 5) |
-                 (((ga < nact ? 1 : 0) | (ga == 0 ? 2 : 0) | (ga == np - 1 ? 4 : 0) | (ga == 1 ? 8 : 0) | 16) << 9);
+        d_info = __builtin_amdgcn_readlane(hcur, 1 + ga);
         if (++ga == np) {
           ++gj;
           ga = 0;
@@ -966,11 +968,11 @@ extern "C" int sf_row_order_size(int n_bound) {
   return ints < 0x7FFFFFFFll ? (int)ints : -1;   // -1: more than 2^31 ints (n_bound beyond ~75 M rows)
 }
 
-extern "C" int sf_row_order_by_mask(const int *nbr, int nbr_stride, int K, const int *n_dev,
+extern "C" int sf_row_order_by_mask(const int *nbr, int nbr_stride, int K, int k_first, const int *n_dev,
                                     int n_bound, int *row_order, void *workspace,
                                     size_t workspace_bytes, void *stream) {
-  return sf_int_row_order(nbr, nbr_stride, K, n_dev, n_bound, row_order, workspace, workspace_bytes, 0,
-                          (hipStream_t)stream);
+  return sf_int_row_order(nbr, nbr_stride, K, k_first, n_dev, n_bound, row_order, workspace, workspace_bytes,
+                          0, (hipStream_t)stream);
 }
 
 // the three per-chunk histogram tables inside a row-order workspace (contiguous)
@@ -982,7 +984,7 @@ void sf_int_row_order_hist(void *workspace, int n_bound, uint32_t **hist, size_t
   *words = 3 * tab / 4;
 }
 
-int sf_int_row_order(const int *nbr, int nbr_stride, int K, const int *n_dev, int n_bound,
+int sf_int_row_order(const int *nbr, int nbr_stride, int K, int k_first, const int *n_dev, int n_bound,
                      int *row_order, void *workspace, size_t workspace_bytes, int hist_ready,
                      hipStream_t st) {
   SF_CHECK_ARG(K >= 1 && K <= kMaxK, "kernel volume %d not in [1,%d]", K, kMaxK);
@@ -1024,7 +1026,7 @@ int sf_int_row_order(const int *nbr, int nbr_stride, int K, const int *n_dev, in
   SF_CHECK_LAUNCH();
   const int tiles = plan_tiles(n_bound);
   hipLaunchKernelGGL(tile_plan_kernel, dim3(sf_grid(tiles, 4)), dim3(256), 0, st, nbr, nbr_stride, K,
-                     n_dev, n_bound, row_order, const_cast<int *>(pv.hdr),
+                     k_first, n_dev, n_bound, row_order, const_cast<int *>(pv.hdr),
                      const_cast<int *>(pv.nbrs), pv.s_stride);
   SF_CHECK_LAUNCH();
   hipLaunchKernelGGL(tile_schedule_kernel, dim3(1), dim3(1024), 0, st, pv.hdr, n_dev, n_bound,

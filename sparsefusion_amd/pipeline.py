@@ -622,7 +622,8 @@ class LidarBackbone:
         """Mask order of the rulebook's output rows, right behind its neighbour table (same stream)."""
         if 'order' in rb:
             _lib.check(self.L.sf_row_order_by_mask(
-                rb['nbr'].data_ptr(), rb['stride'], rb['K'], n_dev, n_bound, rb['order'].data_ptr(),
+                rb['nbr'].data_ptr(), rb['stride'], rb['K'], (rb['K'] - 1) // 2 if rb['subm'] else -1, n_dev, n_bound,
+                rb['order'].data_ptr(),
                 rb['order_ws'].data_ptr(), rb['order_ws_bytes'], stream))
 
     def __call__(self, points_list, voxel_features=None):

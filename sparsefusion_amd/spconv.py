@@ -94,7 +94,7 @@ class Rulebook:
             order = torch.empty(L.sf_row_order_size(n), dtype=torch.int32, device=dev)
             wsb = L.sf_row_order_workspace(n)
             ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-            _lib.check(L.sf_row_order_by_mask(self.nbr.data_ptr(), self.nbr.shape[1], self.K, None,
+            _lib.check(L.sf_row_order_by_mask(self.nbr.data_ptr(), self.nbr.shape[1], self.K, self.k_first, None,
                                               self.out_coords.n, order.data_ptr(), ws.data_ptr(), wsb,
                                               _lib.stream(dev)))
             self._order = order

@@ -24,7 +24,7 @@ def _row_order(rb, dev):
     order = torch.empty(L.sf_row_order_size(max(n, 1)), dtype=torch.int32, device=dev)
     wsb = L.sf_row_order_workspace(max(n, 1))
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-    _lib.check(L.sf_row_order_by_mask(rb.nbr.data_ptr(), rb.nbr.shape[1], rb.K, None, n,
+    _lib.check(L.sf_row_order_by_mask(rb.nbr.data_ptr(), rb.nbr.shape[1], rb.K, rb.k_first, None, n,
                                       order.data_ptr(), ws.data_ptr(), wsb, _lib.stream(dev)))
     return order
 
@@ -54,17 +54,28 @@ def test_row_order_is_a_mask_sorted_permutation(dev, oracle, subm, ks, st, pd):
     nph = np.array([bin(int(np.bitwise_or.reduce(pad[t * 64:(t + 1) * 64]))).count('1') for t in range(tiles)])
     cost = work + 3 * nph                      # a phase costs about three block products of fixed work
     assert np.all(np.diff(cost[sched]) <= 0)
-    # tile headers (active offsets ascending with their 16-row block masks) and the permuted table
+    # tile headers (the tile's phases ready made, in execution order: the centre offset first when it
+    # is active, then the active offsets ascending, padded to three phases) and the permuted table
     hdr = order[n + tiles:n + tiles + 32 * tiles].reshape(tiles, 32)
     tab = order[n + 33 * tiles:n + 33 * tiles + 27 * 64 * tiles].reshape(27, tiles * 64)
     want = np.full((27, tiles * 64), -1, np.int32)
     want[:rb.K, :n] = nbr[:, order[:n]]
     assert np.array_equal(tab[:rb.K], want[:rb.K])
+    kf = rb.k_first
     for t in range(tiles):
         bm = [(want[k, t * 64:(t + 1) * 64].reshape(4, 16) >= 0).any(1) for k in range(rb.K)]
-        act = [(k | (int(sum(int(v) << i for i, v in enumerate(bm[k]))) << 8)) for k in range(rb.K)
-               if bm[k].any()]
-        assert hdr[t, 0] == len(act) and list(hdr[t, 1:1 + len(act)]) == act
+        act = [(k, int(sum(int(v) << i for i, v in enumerate(bm[k])))) for k in range(rb.K) if bm[k].any()]
+        if kf >= 0 and any(k == kf for k, _ in act):
+            act = [a for a in act if a[0] == kf] + [a for a in act if a[0] != kf]
+        npad = max(len(act), 3)
+        words = []
+        for pos in range(npad):
+            flags = (2 if pos == 0 else 0) | (4 if pos == npad - 1 else 0) | (8 if pos == 1 else 0) | 16
+            w = flags << 9
+            if pos < len(act):
+                w |= act[pos][0] | (act[pos][1] << 5) | (1 << 9)
+            words.append(w)
+        assert hdr[t, 0] == npad and list(hdr[t, 1:1 + npad]) == words, t
         assert hdr[t, 28] == cost[t]
 
 
@@ -189,6 +200,6 @@ def test_bad_arguments(dev):
     assert L.sf_sparse_conv_f32_ordered(x.data_ptr(), 64, 16, nbr.data_ptr(), 64, 27, 13, None,
                                         x.data_ptr(), 16, None, None, None, 0, x.data_ptr(), None, 64,
                                         None) < 0       # the plan of sf_row_order_by_mask is required
-    assert L.sf_row_order_by_mask(nbr.data_ptr(), 64, 27, None, 64, x.data_ptr(), x.data_ptr(), 16,
+    assert L.sf_row_order_by_mask(nbr.data_ptr(), 64, 27, 13, None, 64, x.data_ptr(), x.data_ptr(), 16,
                                   None) < 0
     assert b'workspace' in L.sf_last_error()

@@ -73,7 +73,7 @@ def main():
             wsb = L.sf_row_order_workspace(n_bound)
             ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
             t_order = timeit(lambda: _lib.check(L.sf_row_order_by_mask(
-                nbr, stride, K, n_dev, n_bound, order.data_ptr(), ws.data_ptr(), wsb, st)))
+                nbr, stride, K, kf, n_dev, n_bound, order.data_ptr(), ws.data_ptr(), wsb, st)))
             orders[key] = (order, t_order)
         order, t_order = orders[key]
         ref = torch.empty((n_bound, cout), dtype=torch.float32, device=dev)
