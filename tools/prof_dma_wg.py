@@ -54,15 +54,21 @@ def main():
             rc = real(*a)
             torch.cuda.synchronize()
             raw.sf_debug_dma_wg_times(None)
-            res.append((a[2], a[9], L.sf_last_conv_kernel().decode(), buf.cpu().numpy().copy()))
+            res.append((a[2], a[9], L.sf_last_conv_kernel().decode(), buf.cpu().numpy().copy(), a[7], a[16]))
             return rc
         sh = Shim()
         sh.__dict__['sf_sparse_conv_f32_ordered'] = wrapped
         bb.L = sh
         bb.enqueue(f)
         torch.cuda.synchronize()
-    for cin, cout, kern, v in res:
-        g = int((v != 0).sum()) // 2      # starts at [0, g), ends at [g, 2 g)
+    plans = {}
+    for lay in bb.layers:
+        if getattr(lay, 'ordered', False):
+            plans[lay.rb['order'].data_ptr()] = (lay.rb['order'].cpu().numpy(), int(bb.counts[lay.rb['dst']].item()))
+    for cin, cout, kern, v, plan_ptr, n_bound in res:
+        g = 256 if '128, 128' in kern else 768       # resident workgroups of the two instantiations
+        if args.grid_cap:
+            g = min(g, args.grid_cap)
         st, en = v[:g].astype(np.float64), v[g:2 * g].astype(np.float64)
         t0 = st.min()
         span = (en.max() - t0) / 100.0
@@ -71,6 +77,29 @@ def main():
         print(f'{kern}: grid {g} span {span:.1f} us | start spread {(st.max() - t0) / 100:.1f} us | '
               f'end p10 {np.percentile(endr, 10):.1f} p50 {np.percentile(endr, 50):.1f} p90 {np.percentile(endr, 90):.1f} '
               f'max {endr.max():.1f} | mean busy {busy.mean():.1f} us = {busy.mean() / span:.1%} of the span')
+        # the plan's view of the same launch: products and phases of every workgroup, and the least-squares
+        # fit busy = a * products + b * phases + c (c is an extrapolation far outside the data: all
+        # workgroups hold about the same work)
+        plan, n = plans[plan_ptr]
+        tiles_b, tiles = (n_bound + 63) // 64, (n + 63) // 64
+        sched = plan[n_bound:n_bound + tiles_b]
+        hdr = plan[n_bound + tiles_b:n_bound + tiles_b + 32 * tiles_b].reshape(tiles_b, 32)
+        nact_t = np.array([bin(int(m) & 0x7FFFFFF).count('1') for m in hdr[:, 29]])
+        prod_t = hdr[:, 28] - 3 * nact_t
+        ph_t = hdr[:, 0]                 # phases incl. padding
+        wp, wph = np.zeros(g), np.zeros(g)
+        for i in range((tiles + g - 1) // g):
+            for b in range(g):
+                j = i * g + ((g - 1 - b) if (i & 1) else b)
+                if j < tiles:
+                    t = sched[j]
+                    wp[b] += prod_t[t]
+                    wph[b] += ph_t[t]
+        A = np.stack([wp, wph, np.ones(g)], 1)
+        coef, *_ = np.linalg.lstsq(A, busy, rcond=None)
+        pred = A @ coef
+        print(f'    plan: products per workgroup mean {wp.mean():.1f} max {wp.max():.0f}, phases mean {wph.mean():.1f} max {wph.max():.0f} | '
+              f'fit busy = {coef[0]:.3f} us x products + {coef[1]:.3f} us x phases + {coef[2]:.1f} us (rms error {np.sqrt(((pred - busy) ** 2).mean()):.1f} us)')
 
 
 if __name__ == '__main__':
