@@ -729,9 +729,13 @@ conv_f32_dma_kernel(const float *__restrict__ feat, unsigned feat_bytes, PlanVie
       unsigned char *const nxt2 = ph == 0 ? s_b2 : (ph == 1 ? s_b0 : s_b1);   // buffer of phase q+2
       tA = tB; iA = iB; tB = tC; iB = iC; tC = tD; iC = iD;
       next_desc(tD, iD);
-      // issue order (vmcnt retires in order): indices of phase q+3 first, then the rows of phase q+2
-      // -> LDS, so that next phase's wait for the indices does not retire the DMA early
-      {
+      // The phase's own loads -- indices of phase q+3, then the rows of phase q+2 -> LDS (vmcnt
+      // retires in order: indices first, so that next phase's wait for them does not retire the DMA
+      // early) -- are issued BEHIND the first group of MFMAs of a full phase: right after the
+      // barrier both waves of a SIMD would spend ~400 cycles on them with the matrix pipe idle
+      // (measured per wave with s_memtime stamps), one group later each does it while the other
+      // multiplies.
+      auto issue = [&]() {
         int inew[IPW];
         const int *ip = pv.nbrs + (size_t)(iD & 31) * pv.s_stride + (size_t)tD * TM;
 #pragma unroll
@@ -747,7 +751,7 @@ conv_f32_dma_kernel(const float *__restrict__ feat, unsigned feat_bytes, PlanVie
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int j = 0; j < IPW; ++j) ireg[j] = inew[j];
-      }
+      };
       const int fl = iA >> 9;
       if (fl & 2) {            // first phase of a tile
         ++cj;
@@ -760,34 +764,47 @@ conv_f32_dma_kernel(const float *__restrict__ feat, unsigned feat_bytes, PlanVie
         }
         if (tid < kHdrInts && cj + 2 < cnt) hreg = pv.hdr[(size_t)s_tiles[cj + 2] * kHdrInts + tid];
       }
-      if (fl & 1) {
-        const int bmw = (iA >> (5 + rg * MBW)) & ((1 << MBW) - 1);
+      const int bmw = (fl & 1) ? (iA >> (5 + rg * MBW)) & ((1 << MBW) - 1) : 0;
+      {
         auto a_at = [&](int mb, int t) {
           const int p = (rg * MBW + mb) * 16 + ln;
           return *reinterpret_cast<const f32x4 *>(cur + p * ROWB + 16 * ATileF<CIN>::pos(p, 4 * t + g));
         };
-        if (bmw == (1 << MBW) - 1) {
-          f32x4 a[2][MBW];
+        auto group = [&](int t, const f32x4 (&a)[MBW]) {   // the MFMAs of channel group t, all blocks
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mb = 0; mb < MBW; ++mb)
+#pragma unroll
+              for (int i = 0; i < NBW; ++i)
+                acc[mb][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[i][t][j], a[mb][j], acc[mb][i], 0, 0, 0);
+        };
+        const bool full = bmw == (1 << MBW) - 1;
+        f32x4 a[2][MBW];
+        if (full) {   // first channel group of a full phase
 #pragma unroll
           for (int mb = 0; mb < MBW; ++mb) a[0][mb] = a_at(mb, 0);
 #pragma unroll
-          for (int t = 0; t < T; ++t) {
+          for (int mb = 0; mb < MBW; ++mb) a[1][mb] = a_at(mb, 1);
+          __builtin_amdgcn_sched_barrier(0);
+          group(0, a[0]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // ONE copy of the issue block, on every path (the ISA check walks all branches)
+        issue();
+        __builtin_amdgcn_sched_barrier(0);
+        if (full) {
+#pragma unroll
+          for (int t = 1; t < T; ++t) {
             if (t + 1 < T) {
 #pragma unroll
               for (int mb = 0; mb < MBW; ++mb) a[(t + 1) & 1][mb] = a_at(mb, t + 1);
             }
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-              for (int mb = 0; mb < MBW; ++mb)
-#pragma unroll
-                for (int i = 0; i < NBW; ++i)
-                  acc[mb][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[i][t][j], a[t & 1][mb][j],
-                                                                   acc[mb][i], 0, 0, 0);
+            group(t, a[t & 1]);
             __builtin_amdgcn_sched_barrier(0);
           }
-        } else if (bmw != 0) {
+        } else {
 #pragma unroll
           for (int mb = 0; mb < MBW; ++mb)
             if ((bmw >> mb) & 1) {  // uniform
