@@ -652,8 +652,28 @@ conv_f32_dma_kernel(const float *__restrict__ feat, unsigned feat_bytes, PlanVie
   (void)k_first;   // the summation order (centre first) is part of the plan: sf_row_order_by_mask
   const int tiles = (n_out + TM - 1) / TM;
   const int G = gridDim.x, b = blockIdx.x;
+  // The schedule (tiles by descending cost) is dealt in rounds, snake order: `full` rounds of whole
+  // tiles, then ONE more round for the `rem` tiles left over (the lightest ones): as many of them as
+  // it takes are dealt as HALF tiles (16-row blocks 0-1 / 2-3 of the tile) so that the round has an
+  // entry for every workgroup, or, when rem <= G / 2, all of them are.  With 1.5 tiles per workgroup
+  // (frames 1-3 of the synthetic stream at stage 4: 380 tiles on 256 workgroups) half of the
+  // workgroups held two tiles and the others one: mean busy 79-83 % of the launch.  A half tile pays
+  // the per-phase work of a whole one for half the products, so no more tiles are split than needed.
+  // Only with ONE workgroup per CU: with three (64 channels) an early finisher speeds up its CU mates
+  // and the halves' extra phases cost more than they level (measured 117.0 vs 114.9 us).
+  constexpr bool kSplit = MINB == 1;
   const int full = tiles / G, rem = tiles - full * G;
-  const int my_n = full + ((((full & 1) ? G - 1 - b : b) < rem) ? 1 : 0);
+  const int whole = !kSplit ? rem : (2 * rem > G ? 2 * rem - G : 0);   // leftover tiles dealt whole (the heavier ones)
+  const int last_entries = whole + 2 * (rem - whole);     // = G when rem > G / 2, else 2 * rem
+  const int snake_last = (full & 1) ? G - 1 - b : b;
+  const int my_n = full + (snake_last < last_entries ? 1 : 0);
+  // entry i of this workgroup: tile | owned 16-row blocks << 24
+  auto entry = [&](int i) -> int {
+    if (i < full) return pv.sched[(size_t)i * G + ((i & 1) ? G - 1 - b : b)] | (0xF << 24);
+    if (snake_last < whole) return pv.sched[(size_t)full * G + snake_last] | (0xF << 24);
+    const int h = snake_last - whole;
+    return pv.sched[(size_t)full * G + whole + (h >> 1)] | (((h & 1) ? 0xC : 0x3) << 24);
+  };
   if (wg_times && tid == 0) wg_times[b] = wall_clock64();
 
   f32x4 acc[MBW][NBW];
@@ -687,16 +707,13 @@ conv_f32_dma_kernel(const float *__restrict__ feat, unsigned feat_bytes, PlanVie
     // and nothing the compiler knows of makes the barrier below wait for them
     __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0)
     __syncthreads();
-    if (tid < cnt) {
-      const int i = run0 + tid;
-      s_tiles[tid] = pv.sched[(size_t)i * G + ((i & 1) ? G - 1 - b : b)];
-    }
+    if (tid < cnt) s_tiles[tid] = entry(run0 + tid);
     // (every barrier of this kernel follows an explicit vector-memory wait: the set-up barriers a
     // full drain, the phase barriers the counted one -- tests/test_isa_dma_wait.py holds the ISA to it)
     __builtin_amdgcn_s_waitcnt(0x0070);
     __syncthreads();
     if (tid < 2 * kHdrInts && (tid >> 5) < cnt)
-      s_hdr[tid] = pv.hdr[(size_t)s_tiles[tid >> 5] * kHdrInts + (tid & 31)];
+      s_hdr[tid] = pv.hdr[(size_t)(s_tiles[tid >> 5] & 0xFFFFFF) * kHdrInts + (tid & 31)];
     __builtin_amdgcn_s_waitcnt(0x0070);
     __syncthreads();
 
@@ -737,15 +754,19 @@ conv_f32_dma_kernel(const float *__restrict__ feat, unsigned feat_bytes, PlanVie
       // multiplies.
       auto issue = [&]() {
         int inew[IPW];
-        const int *ip = pv.nbrs + (size_t)(iD & 31) * pv.s_stride + (size_t)tD * TM;
+        const int *ip = pv.nbrs + (size_t)(iD & 31) * pv.s_stride + (size_t)(tD & 0xFFFFFF) * TM;
 #pragma unroll
         for (int j = 0; j < IPW; ++j) inew[j] = ip[prow[j]];
         // a padding phase fetches row -1: out of range, zeros land in LDS, no fetch.  (An OR with a
-        // scalar mask, not a select: the select became a branch around the first DMA.)
+        // scalar mask, not a select: the select became a branch around the first DMA.)  So do the
+        // rows of 16-row blocks a half tile does not own.
         const unsigned dead = ((iC >> 9) & 1) ? 0u : 0xFFFFFFFFu;
+        const unsigned own = (unsigned)tC >> 24;
 #pragma unroll
-        for (int j = 0; j < IPW; ++j)
-          lds_dma16(rs, nxt2 + (wave * IPW + j) * 1024, ((unsigned)ireg[j] | dead) * ROWB + soff[j]);
+        for (int j = 0; j < IPW; ++j) {
+          const unsigned skip = dead | (((own >> (prow[j] >> 4)) & 1u) - 1u);
+          lds_dma16(rs, nxt2 + (wave * IPW + j) * 1024, ((unsigned)ireg[j] | skip) * ROWB + soff[j]);
+        }
         // compiler fence (no instruction): the memory operations below stay below the DMA, the
         // order kWaitN counts on (tests/test_isa_dma_wait.py checks the emitted ISA)
         asm volatile("" ::: "memory");
@@ -757,14 +778,15 @@ conv_f32_dma_kernel(const float *__restrict__ feat, unsigned feat_bytes, PlanVie
         ++cj;
 #pragma unroll
         for (int mb = 0; mb < MBW; ++mb) {
-          const int e = tA * TM + (rg * MBW + mb) * 16 + ln;
-          orow[mb] = e < n_out ? pv.order[e] : -1;
+          const int e = (tA & 0xFFFFFF) * TM + (rg * MBW + mb) * 16 + ln;
+          orow[mb] = (e < n_out && (((unsigned)tA >> (24 + rg * MBW + mb)) & 1u)) ? pv.order[e] : -1;
 #pragma unroll
           for (int i = 0; i < NBW; ++i) acc[mb][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        if (tid < kHdrInts && cj + 2 < cnt) hreg = pv.hdr[(size_t)s_tiles[cj + 2] * kHdrInts + tid];
+        if (tid < kHdrInts && cj + 2 < cnt)
+          hreg = pv.hdr[(size_t)(s_tiles[cj + 2] & 0xFFFFFF) * kHdrInts + tid];
       }
-      const int bmw = (fl & 1) ? (iA >> (5 + rg * MBW)) & ((1 << MBW) - 1) : 0;
+      const int bmw = (fl & 1) ? ((iA >> 5) & ((unsigned)tA >> 24) & 15) >> (rg * MBW) & ((1 << MBW) - 1) : 0;
       {
         auto a_at = [&](int mb, int t) {
           const int p = (rg * MBW + mb) * 16 + ln;

@@ -166,6 +166,59 @@ def test_many_tiles_per_workgroup(dev, oracle, cin, cout, cap, batch):
     assert np.array_equal(outs[0], outs[1])          # same sums in the same order, whatever the grid
 
 
+def test_leftover_tiles_dealt_as_halves(dev, oracle):
+    """The 128 -> 128 kernel (one workgroup per CU) deals the tiles left over after the whole rounds
+    of its schedule as HALF tiles (16-row blocks 0-1 / 2-3), as many as it takes to give every
+    workgroup an entry.  Grid caps from 3 to 64 workgroups over one problem hit every pattern --
+    nothing left over, all leftovers split (rem <= G / 2), whole and split leftovers mixed -- with
+    residual and ReLU; every grid must give the SAME bits (the summation order per output element does
+    not depend on the schedule) and the oracle's values."""
+    import ctypes
+    rng = np.random.default_rng(4128)
+    cin = cout = 128
+    coors = _coords(oracle, 77, 4000)
+    n = coors.shape[0]
+    tiles = (n + 63) // 64
+    feats = rng.normal(0, 1, (n, cin)).astype(np.float32)
+    res = rng.normal(0, 1, (n, cout)).astype(np.float32)
+    w = (rng.uniform(-1, 1, (27, cin, cout)) * np.sqrt(3.0 / (9 * cin))).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = rng.normal(0, 0.1, cout).astype(np.float32)
+    outids, pairs, num, _ = oracle.get_indice_pairs(coors, 1, SMALL_SHAPE, 3, 1, 1, 1, True)
+    expect = np.maximum(oracle.indice_conv(feats, w, pairs, num, n, True) * scale + shift + res, 0)
+    cs = spconv.CoordSet(to_dev(coors, dev), SMALL_SHAPE, 1)
+    rb = spconv.build_rulebook(cs, 3, 1, 1, 1, True)
+    L = _lib.lib()
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    raw.sf_debug_ordered_grid_cap.argtypes = [ctypes.c_int]
+    d_feats, d_w, d_res = to_dev(feats, dev), spconv.pack_filters(to_dev(w, dev)), to_dev(res, dev)
+    d_scale, d_shift = to_dev(scale, dev), to_dev(shift, dev)
+    order = _row_order(rb, dev)
+    caps = [0, 3, 4, 5, 7, 8, 16, 33, 64] + [c for c in (tiles, tiles - 1, (tiles + 1) // 2) if c > 2]
+    patterns, first = set(), None
+    for c in caps:
+        g = min(c, 256) if c else min(tiles, 256)
+        rem = tiles % g
+        patterns.add('none' if rem == 0 else ('all split' if 2 * rem <= g else 'mixed'))
+        out = torch.full((n, cout), np.nan, dtype=torch.float32, device=dev)
+        raw.sf_debug_ordered_grid_cap(c)
+        try:
+            _lib.check(L.sf_sparse_conv_f32_ordered(
+                d_feats.data_ptr(), n, cin, rb.nbr.data_ptr(), rb.nbr.shape[1], rb.K, rb.k_first,
+                order.data_ptr(), d_w.data_ptr(), cout, d_scale.data_ptr(), d_shift.data_ptr(),
+                d_res.data_ptr(), 1, out.data_ptr(), None, n, _lib.stream(dev)))
+            torch.cuda.synchronize()
+        finally:
+            raw.sf_debug_ordered_grid_cap(0)
+        assert L.sf_last_conv_kernel().decode().startswith('conv_f32_dma_kernel<128, 128')
+        got = out.cpu().numpy()
+        if first is None:
+            first = got
+            assert_close(got, expect.astype(np.float32))
+        assert np.array_equal(got, first), c
+    assert patterns == {'none', 'all split', 'mixed'}, patterns
+
+
 def test_pipeline_with_the_ordered_kernel(dev, oracle, monkeypatch):
     """LidarBackbone with every eligible layer on the ordered kernel (spconv.ORDERED_SHAPES = 'all'), device
     row counts, captured in a HIP graph: BEV map against the oracle."""

@@ -31,6 +31,9 @@ def main():
                     help='create the wide-layer stream with this priority (-1 = high) instead of '
                          'taking it from the probed pool')
     ap.add_argument('--quiet', action='store_true', help='totals only')
+    ap.add_argument('--wg-times', action='store_true',
+                    help='capture with sf_debug_dma_wg_times set: after the run, how level the workgroups of the LAST '
+                         '128->128 launch finished INSIDE the running pipeline')
     ap.add_argument('--light-cus', type=int, default=0,
                     help='create the two light streams with a CU mask of this many CUs (hipExtStreamCreateWithCUMask)')
     ap.add_argument('--wide-rest', action='store_true', help='with --light-cus: the wide stream on the other CUs only')
@@ -65,6 +68,14 @@ def main():
         print('wide stream priority', wide.priority, 'range', torch.cuda.Stream.priority_range())
     print('hardware queues found', nq, flush=True)
     frames = [[torch.from_numpy(p).to(dev)] for p in host]
+    wg_buf = None
+    if args.wg_times:
+        import ctypes
+        from sparsefusion_amd import _lib
+        raw = ctypes.CDLL(_lib.LIB_PATH)
+        raw.sf_debug_dma_wg_times.argtypes = [ctypes.c_void_p]
+        wg_buf = torch.zeros(2 * 4096, dtype=torch.int64, device=dev)
+        raw.sf_debug_dma_wg_times(wg_buf.data_ptr())
     sfs = []
     with torch.no_grad():
         for li, lane in enumerate(lanes):
@@ -112,6 +123,15 @@ def main():
         t2 = time.perf_counter()
         print(f'round {rnd}: host submit {1e3 * (t1 - t0):.2f} ms, all done {1e3 * (t2 - t0):.2f} ms '
               f'= {1e3 * (t2 - t0) / args.frames:.3f} ms/frame')
+    if wg_buf is not None:
+        v = wg_buf.cpu().numpy()
+        g = 256
+        st, en = v[:g].astype(np.float64), v[g:2 * g].astype(np.float64)
+        t0 = st.min()
+        endr, busy = (en - t0) / 100.0, (en - st) / 100.0
+        print(f'last 128->128 launch inside the pipeline: span {endr.max():.1f} us | start spread {(st.max() - t0) / 100:.1f} us | '
+              f'workgroup ends p10 {np.percentile(endr, 10):.1f} p50 {np.percentile(endr, 50):.1f} p90 {np.percentile(endr, 90):.1f} '
+              f'max {endr.max():.1f} | busy mean {busy.mean():.1f} min {busy.min():.1f} max {busy.max():.1f} us = {busy.mean() / endr.max():.1%} of the span')
     if args.quiet:
         return
     print('frame: host submit [ms from t0] (wait_event, replay calls) | light seg GPU start..end | wide seg GPU start..end')

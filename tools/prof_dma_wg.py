@@ -82,6 +82,7 @@ def main():
         # workgroups hold about the same work)
         plan, n = plans[plan_ptr]
         tiles_b, tiles = (n_bound + 63) // 64, (n + 63) // 64
+        print(f'    rows {n}, tiles {tiles}: {tiles // g} whole rounds on {g} workgroups + {tiles % g} tiles left over')
         sched = plan[n_bound:n_bound + tiles_b]
         hdr = plan[n_bound + tiles_b:n_bound + tiles_b + 32 * tiles_b].reshape(tiles_b, 32)
         nact_t = np.array([bin(int(m) & 0x7FFFFFF).count('1') for m in hdr[:, 29]])
