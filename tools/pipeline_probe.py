@@ -31,6 +31,9 @@ def main():
                     help='create the wide-layer stream with this priority (-1 = high) instead of '
                          'taking it from the probed pool')
     ap.add_argument('--quiet', action='store_true', help='totals only')
+    ap.add_argument('--wide-streams', type=int, default=1,
+                    help='2: the wide layers of even / odd frames on two streams (the tail of one frame\'s kernel is '
+                         'filled by the other frame\'s)')
     ap.add_argument('--wg-times', action='store_true',
                     help='capture with sf_debug_dma_wg_times set: after the run, how level the workgroups of the LAST '
                          '128->128 launch finished INSIDE the running pipeline')
@@ -60,6 +63,8 @@ def main():
         l0, l1, wide = masked(lo), masked(lo), masked(hi if args.wide_rest else (1 << 256) - 1)
         nq = 3
         print('CU masks: light', args.light_cus, 'CUs, wide', 'the rest' if args.wide_rest else 'all')
+    elif args.wide_streams == 2:
+        (l0, l1, wide, wide1), nq = concurrent_streams(dev, 4)
     elif args.wide_priority is None:
         (l0, l1, wide), nq = concurrent_streams(dev, 3)
     else:
@@ -80,7 +85,8 @@ def main():
     with torch.no_grad():
         for li, lane in enumerate(lanes):
             light = (l0, l1)[li % 2]
-            sfs.append([lane.capture_split(f, [light, light, wide]) for f in frames])
+            w_ = wide1 if (args.wide_streams == 2 and li % 2) else wide
+            sfs.append([lane.capture_split(f, [light, light, w_]) for f in frames])
     torch.cuda.synchronize()
 
     base = torch.cuda.Event(enable_timing=True)
