@@ -300,17 +300,33 @@ tile_schedule_kernel(const int *__restrict__ hdr, const int *n_dev, int n_bound,
   for (int t = threadIdx.x; t < tiles; t += 1024)
     atomicAdd(&s_cnt[kCostBins - 1 - hdr[(size_t)t * kHdrInts + 28]], 1);
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int run = 0, sum = 0;
-    for (int i = 0; i < kCostBins; ++i) {
-      const int c = s_cnt[i];
-      s_cnt[i] = run;
-      s_start[i] = run;
-      s_base[i] = sum;
-      run += c;
-      sum += c * (kCostBins - 1 - i);
+  // exclusive prefix sums over the bins (tiles in front, their cost): Hillis-Steele over 512 threads
+  {
+    const int i = threadIdx.x;
+    const int c = i < kCostBins ? s_cnt[i] : 0;
+    if (i < kCostBins) {
+      s_start[i] = c;
+      s_base[i] = c * (kCostBins - 1 - i);
     }
-    cum[tiles] = sum;
+    __syncthreads();
+    for (int d = 1; d < kCostBins; d <<= 1) {
+      const int a = (i < kCostBins && i >= d) ? s_start[i - d] : 0;
+      const int v = (i < kCostBins && i >= d) ? s_base[i - d] : 0;
+      __syncthreads();
+      if (i < kCostBins) {
+        s_start[i] += a;
+        s_base[i] += v;
+      }
+      __syncthreads();
+    }
+    if (i == kCostBins - 1) cum[tiles] = s_base[i];
+    __syncthreads();
+    if (i < kCostBins) {          // inclusive -> exclusive
+      const int a = s_start[i] - c, v = s_base[i] - c * (kCostBins - 1 - i);
+      s_start[i] = a;
+      s_base[i] = v;
+      s_cnt[i] = a;
+    }
   }
   __syncthreads();
   // equal weights keep no particular order (the schedule affects timing only, never results)
@@ -638,7 +654,7 @@ conv_f32_dma_kernel(const float *__restrict__ feat, unsigned feat_bytes, PlanVie
                     int k_first, const f32x4 *__restrict__ wp, const float *__restrict__ scale,
                     const float *__restrict__ shift, const float *__restrict__ residual, int relu,
                     float *__restrict__ out, const int *n_out_dev, int n_out_bound,
-                    unsigned long long *__restrict__ wg_times) {
+                    unsigned long long *__restrict__ wg_times, int force_slices) {
   constexpr int TM = kTileRows, T = CIN / 16, ROWB = CIN * 4, CH = CIN / 4;
   constexpr int NB = COUT / 16, NBW = NB / CG, RG = WAVES / CG, MBT = TM / 16, MBW = MBT / RG;
   constexpr int RPI = 1024 / ROWB;             // rows one DMA instruction covers
@@ -686,7 +702,17 @@ conv_f32_dma_kernel(const float *__restrict__ feat, unsigned feat_bytes, PlanVie
   const int full = tiles / G, rem = tiles - full * G;
   int my_n = full + (((full & 1) ? G - 1 - b : b) < rem ? 1 : 0);
   int i_s = 0, c_s = 0, i_e = 0, c_e = 0, head = 0;   // slice = [(i_s, c_s), (i_e, c_e)) in (position, phase)
+  // Slices only where they pay: a slice at least as long as the heaviest tile (a longer tile would run
+  // as a chain of parts, as slow as the whole tile plus the hand-overs: measured 134 against 121 us on
+  // the Waymo-shaped frame, 173 tiles on 173 workgroups) and fewer than four tiles per workgroup (with
+  // more the snake rounds level within one light tile, and every workgroup gets the same mix of heavy
+  // and light tiles, which the cost scale does not have to get right: B=8, 16 tiles per workgroup).
+  bool slices = false;
   if constexpr (kSplit) {
+    if (tiles > 0 && tiles < 4 * G) slices = pv.cum[tiles] / G >= pv.cum[1];
+    if (force_slices && tiles > 0) slices = true;   // test hook: chains of three and more parts
+  }
+  if (slices) {
     __shared__ int s_cut[2];
     const int total = pv.cum[tiles];
     const int lo = (int)((long long)total * b / G), hi = (int)((long long)total * (b + 1) / G);
@@ -737,7 +763,7 @@ conv_f32_dma_kernel(const float *__restrict__ feat, unsigned feat_bytes, PlanVie
   // entry i of this workgroup: position in the schedule -> tile | kind << 24; kind bit 0: the part
   // ends at phase c_e, before the tile does (producer), bit 1: it starts at phase c_s (consumer)
   auto entry = [&](int i) -> int {
-    if constexpr (kSplit) {
+    if (slices) {
       if (i_s == i_e) return pv.sched[i_s] | ((1 | (c_s > 0 ? 2 : 0)) << 24);
       if (head) {
         if (i == 0) return pv.sched[i_e] | (1 << 24);
@@ -1037,6 +1063,7 @@ conv_f32_dma_kernel(const float *__restrict__ feat, unsigned feat_bytes, PlanVie
 unsigned long long *g_ord_prof = nullptr;
 unsigned long long *g_dma_wg_times = nullptr;   // diagnostic only, see sf_debug_dma_wg_times   // diagnostic only, see sf_debug_ordered_profile
 int g_ord_grid_cap = 0;                     // test hook, see sf_debug_ordered_grid_cap (0 = off)
+int g_ord_force_slices = 0;                 // test hook: a negative cap forces the slice schedule
 
 struct OrdArgs {
   const float *feat;
@@ -1096,7 +1123,7 @@ int launch_dma(const OrdArgs &a) {
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), 0, a.st, a.feat, a.feat_bytes,
                      plan_view(a.plan, a.n_out_bound), a.K, a.k_first,
                      reinterpret_cast<const f32x4 *>(a.wpk), a.scale, a.shift, a.residual, a.relu,
-                     a.out, a.n_out_dev, a.n_out_bound, g_dma_wg_times);
+                     a.out, a.n_out_dev, a.n_out_bound, g_dma_wg_times, g_ord_force_slices);
   SF_CHECK_LAUNCH();
   return SF_OK;
 }
@@ -1260,7 +1287,10 @@ extern "C" __attribute__((visibility("default"))) void sf_debug_dma_wg_times(voi
 
 // Test hook (not part of the documented ABI): limits the grid of the ordered / DMA kernels to `cap`
 // persistent workgroups (0 = off), so that a small problem gives a workgroup more than kRun tiles
-// (tests/test_gpu_conv_ordered.py::test_many_tiles_per_workgroup).  Process-wide, not thread-safe.
+// (tests/test_gpu_conv_ordered.py::test_many_tiles_per_workgroup).  A NEGATIVE cap limits the grid to
+// -cap and makes the 128-channel DMA kernel use its slice schedule whatever the tile count (a slice
+// shorter than a tile: chains of three and more parts).  Process-wide, not thread-safe.
 extern "C" __attribute__((visibility("default"))) void sf_debug_ordered_grid_cap(int cap) {
-  g_ord_grid_cap = cap > 0 ? cap : 0;
+  g_ord_grid_cap = cap > 0 ? cap : (cap < 0 ? -cap : 0);
+  g_ord_force_slices = cap < 0;
 }

@@ -199,7 +199,11 @@ def test_tiles_cut_by_phases_between_workgroups(dev, oracle):
     d_scale, d_shift = to_dev(scale, dev), to_dev(shift, dev)
     order = _row_order(rb, dev)
     assert tiles > 16, tiles
-    caps = [1, 2, 3, 4, 5, 7, 8, 16, 33, 64, 0, tiles - 1, (tiles + 1) // 2, (2 * tiles) // 3]
+    # a negative cap forces the slice schedule (the kernel itself takes it only when a slice is at least
+    # as long as the heaviest tile and a workgroup has fewer than four tiles): -(tiles) and -(tiles - 1)
+    # give slices shorter than the heavy tiles, i.e. chains of three and more parts
+    caps = [1, 2, 3, 4, 5, 7, 8, 16, 33, 64, 0, (tiles + 1) // 2, (2 * tiles) // 3,
+            -2, -3, -5, -16, -33, -((tiles + 1) // 2), -(tiles - 1), -tiles, -256]
     first = None
     for c in caps:
         for rep in range(2):

@@ -40,6 +40,8 @@ def main():
     ap.add_argument('--light-cus', type=int, default=0,
                     help='create the two light streams with a CU mask of this many CUs (hipExtStreamCreateWithCUMask)')
     ap.add_argument('--wide-rest', action='store_true', help='with --light-cus: the wide stream on the other CUs only')
+    ap.add_argument('--ordered-grid-cap', type=int, default=0,
+                    help='sf_debug_ordered_grid_cap while capturing: the persistent grid of the mask-ordered kernels')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     torch.cuda.set_device(dev)
@@ -81,6 +83,12 @@ def main():
         raw.sf_debug_dma_wg_times.argtypes = [ctypes.c_void_p]
         wg_buf = torch.zeros(2 * 4096, dtype=torch.int64, device=dev)
         raw.sf_debug_dma_wg_times(wg_buf.data_ptr())
+    if args.ordered_grid_cap:
+        import ctypes
+        from sparsefusion_amd import _lib
+        raw_cap = ctypes.CDLL(_lib.LIB_PATH)
+        raw_cap.sf_debug_ordered_grid_cap.argtypes = [ctypes.c_int]
+        raw_cap.sf_debug_ordered_grid_cap(args.ordered_grid_cap)
     sfs = []
     with torch.no_grad():
         for li, lane in enumerate(lanes):
