@@ -367,17 +367,14 @@ SF_API int sf_row_order_size(int n_bound);
  *   [0, n_bound)            the output rows sorted (stably) by their K-bit neighbour mask (bit k set
  *                           <=> nbr[k][row] >= 0); entries [*n_dev, n_bound) are -1 or unspecified
  *   [n_bound, +T)           the tile schedule: the 64-row tiles of the sorted rows by descending cost
- *                           (3 per (16-row block, offset) product + 4 per phase), dealt to the
+ *                           ((16-row block, offset) products + 3 per active offset), dealt to the
  *                           persistent workgroups of the convolution
  *   + 32 T                  tile headers: [0] phases np = max(active offsets, 3), [1..np] the phases
  *                           ready made in execution order -- the offset k_first (the centre of a
  *                           SubM rulebook; -1: none) first when active, then ascending, then
  *                           padding: k | block mask << 5 | flags << 9 --, [28] cost, [29] mask of
- *                           the active offsets, [30] hand-over word of the convolution kernel (0
- *                           between launches; WRITTEN by sf_sparse_conv_f32_ordered while it runs)
+ *                           the active offsets
  *   + 27 * 64 T             the neighbour table permuted into the sorted order, column per offset
- *   + T + 1                 running sum of the tile costs in schedule order (the 128-channel kernel
- *                           gives every workgroup an equal slice of it, cutting tiles by phases)
  * The buffer holds sf_row_order_size(n_bound) ints.  The sort is a hand-written 3-pass radix sort
  * bounded by the device-side row count (no library call, no host synchronisation); seven short
  * launches per rulebook.
@@ -398,10 +395,7 @@ SF_API int sf_row_order_by_mask(const int *nbr, int nbr_stride, int K, int k_fir
  * offsets ascending), independent of row_order; the order is part of the plan (k_first of
  * sf_row_order_by_mask), k_first here must be the same value.  features_in is (n_in_bound, cin_padded) f32
  * with cin_padded in {16, 32, 64, 128}: n_in_bound rows must be addressable (the gather is bounds
- * checked against it; table < 4 GiB).  out must not alias features_in or residual, and two launches
- * over ONE plan must not overlap in time (launches on one stream never do): at 128 -> 128 channels
- * a tile cut between two workgroups parks its raw sums in its output rows and hands over through
- * the plan's header words, which is why row_order, though declared const, is scratch in that word. */
+ * checked against it; table < 4 GiB). */
 SF_API int sf_sparse_conv_f32_ordered(const float *features_in, int n_in_bound, int cin_padded,
                                       const int *nbr, int nbr_stride, int K, int k_first,
                                       const int *row_order, const float *w_packed, int cout,

@@ -271,75 +271,44 @@ tile_plan_kernel(const int *__restrict__ nbr, int nbr_stride, int K, int k_first
     for (int d = 1; d < 64; d <<= 1) w += __shfl_xor(w, d, 64);
     if (lane == 0) {
       h[0] = np;
-      // cost of the tile for the schedule: 3 per (16-row block, offset) product + 4 per phase, padding
-      // phases included (measured per tile at 128 channels: 0.863 us x products + 1.126 us x phases:
-      // descriptor, loads, barrier).  A phase of the header costs 3 popc(block mask) + 4: the
-      // kernel cuts tiles between workgroups on this scale.
-      h[28] = 3 * w + 4 * np;
+      // cost of the tile for the schedule: a phase costs about three block products of fixed work
+      // (descriptor, loads, barrier) besides its products; balancing products alone left the
+      // workgroups up to 1.5x apart in phases (tools: LPT simulation on the frame's real masks)
+      h[28] = w + 3 * nact;
       h[29] = (int)act;
-      h[30] = 0;   // hand-over word of a tile split between two workgroups (conv_f32_dma_kernel)
     }
   }
 }
 
-// Tile schedule = tiles by descending cost (counting sort over the <= 433 distinct values, one
-// workgroup) + the running sum of the costs in that order (cum[i] = cost of the tiles in front of
-// position i, cum[tiles] = all).  The register-staged kernels and the 64-channel DMA kernel deal the
-// order to their persistent workgroups in snake rounds (a longest-processing-time assignment: the
-// heaviest tiles are spread first, the light ones level the tails); the 128-channel DMA kernel
-// gives workgroup b the slice [b, b + 1) x (all / G) of the running sum, cutting tiles by phases.
-constexpr int kCostBins = 512;   // cost <= 3 * 108 + 4 * 27
+// Tile schedule = tiles by descending cost (counting sort over the <= 190 distinct values, one
+// workgroup).  Dealt to the persistent workgroups in snake order it is a longest-processing-time
+// assignment: the heaviest tiles are spread first, the light ones level the tails.
 __global__ void __launch_bounds__(1024)
 tile_schedule_kernel(const int *__restrict__ hdr, const int *n_dev, int n_bound,
-                     int *__restrict__ sched, int *__restrict__ cum) {
-  __shared__ int s_cnt[kCostBins], s_start[kCostBins], s_base[kCostBins];
+                     int *__restrict__ sched) {
+  __shared__ int s_cnt[256];   // cost <= 108 + 3 * 27
   const int n = load_n(n_dev, n_bound);
   const int tiles = (n + kTileRows - 1) / kTileRows;
-  if (threadIdx.x < kCostBins) s_cnt[threadIdx.x] = 0;
+  if (threadIdx.x < 256) s_cnt[threadIdx.x] = 0;
   __syncthreads();
-  for (int t = threadIdx.x; t < tiles; t += 1024)
-    atomicAdd(&s_cnt[kCostBins - 1 - hdr[(size_t)t * kHdrInts + 28]], 1);
+  for (int t = threadIdx.x; t < tiles; t += 1024) atomicAdd(&s_cnt[255 - hdr[(size_t)t * kHdrInts + 28]], 1);
   __syncthreads();
-  // exclusive prefix sums over the bins (tiles in front, their cost): Hillis-Steele over 512 threads
-  {
-    const int i = threadIdx.x;
-    const int c = i < kCostBins ? s_cnt[i] : 0;
-    if (i < kCostBins) {
-      s_start[i] = c;
-      s_base[i] = c * (kCostBins - 1 - i);
-    }
-    __syncthreads();
-    for (int d = 1; d < kCostBins; d <<= 1) {
-      const int a = (i < kCostBins && i >= d) ? s_start[i - d] : 0;
-      const int v = (i < kCostBins && i >= d) ? s_base[i - d] : 0;
-      __syncthreads();
-      if (i < kCostBins) {
-        s_start[i] += a;
-        s_base[i] += v;
-      }
-      __syncthreads();
-    }
-    if (i == kCostBins - 1) cum[tiles] = s_base[i];
-    __syncthreads();
-    if (i < kCostBins) {          // inclusive -> exclusive
-      const int a = s_start[i] - c, v = s_base[i] - c * (kCostBins - 1 - i);
-      s_start[i] = a;
-      s_base[i] = v;
-      s_cnt[i] = a;
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int i = 0; i < 256; ++i) {
+      const int c = s_cnt[i];
+      s_cnt[i] = run;
+      run += c;
     }
   }
   __syncthreads();
   // equal weights keep no particular order (the schedule affects timing only, never results)
-  for (int t = threadIdx.x; t < tiles; t += 1024) {
-    const int bin = kCostBins - 1 - hdr[(size_t)t * kHdrInts + 28];
-    const int pos = atomicAdd(&s_cnt[bin], 1);
-    sched[pos] = t;
-    cum[pos] = s_base[bin] + (pos - s_start[bin]) * (kCostBins - 1 - bin);
-  }
+  for (int t = threadIdx.x; t < tiles; t += 1024)
+    sched[atomicAdd(&s_cnt[255 - hdr[(size_t)t * kHdrInts + 28]], 1)] = t;
 }
 
 struct PlanView {
-  const int *order, *sched, *hdr, *nbrs, *cum;
+  const int *order, *sched, *hdr, *nbrs;
   int s_stride;
 };
 
@@ -654,7 +623,7 @@ conv_f32_dma_kernel(const float *__restrict__ feat, unsigned feat_bytes, PlanVie
                     int k_first, const f32x4 *__restrict__ wp, const float *__restrict__ scale,
                     const float *__restrict__ shift, const float *__restrict__ residual, int relu,
                     float *__restrict__ out, const int *n_out_dev, int n_out_bound,
-                    unsigned long long *__restrict__ wg_times, int force_slices) {
+                    unsigned long long *__restrict__ wg_times) {
   constexpr int TM = kTileRows, T = CIN / 16, ROWB = CIN * 4, CH = CIN / 4;
   constexpr int NB = COUT / 16, NBW = NB / CG, RG = WAVES / CG, MBT = TM / 16, MBW = MBT / RG;
   constexpr int RPI = 1024 / ROWB;             // rows one DMA instruction covers
@@ -683,97 +652,27 @@ conv_f32_dma_kernel(const float *__restrict__ feat, unsigned feat_bytes, PlanVie
   (void)k_first;   // the summation order (centre first) is part of the plan: sf_row_order_by_mask
   const int tiles = (n_out + TM - 1) / TM;
   const int G = gridDim.x, b = blockIdx.x;
-  // Who does what.  With several workgroups per CU (64 channels) the schedule (tiles by descending
-  // cost) is dealt in snake rounds of whole tiles: an early finisher speeds up its CU mates there.
-  // With ONE workgroup per CU (kSplit, 128 channels) whole tiles left the workgroups 79-83 % busy
-  // (380 tiles on 256 workgroups: half of them hold two tiles, the others one), so workgroup b takes
-  // the slice [b, b + 1) x (all / G) of the RUNNING SUM of the tile costs over the schedule, and a
-  // tile the slice boundary falls into is cut BY PHASES: the lower workgroup multiplies the
-  // phases in front of the cut and stores the raw sums into the tile's output rows, the upper one
-  // continues the same FMA chains from them (same bits as one workgroup doing all of it) and does
-  // the epilogue.  Hand-over through word 30 of the tile's header = the number of phases done
-  // (release / acquire at agent scope: the two workgroups sit on different XCDs).  A workgroup runs
-  // the part it STARTS (the head of the tile at the top of its slice) first and the part it has to
-  // wait for (the rest of the tile at the bottom of its slice) last, so nobody waits unless a tile
-  // is longer than a slice (then its parts run in sequence, as the whole tile would have); the
-  // producer has the lower index, so with workgroups dispatched in index order a waiting
-  // workgroup's producer is running or done.
+  // The schedule (tiles by descending cost) is dealt in rounds, snake order: `full` rounds of whole
+  // tiles, then ONE more round for the `rem` tiles left over (the lightest ones): as many of them as
+  // it takes are dealt as HALF tiles (16-row blocks 0-1 / 2-3 of the tile) so that the round has an
+  // entry for every workgroup, or, when rem <= G / 2, all of them are.  With 1.5 tiles per workgroup
+  // (frames 1-3 of the synthetic stream at stage 4: 380 tiles on 256 workgroups) half of the
+  // workgroups held two tiles and the others one: mean busy 79-83 % of the launch.  A half tile pays
+  // the per-phase work of a whole one for half the products, so no more tiles are split than needed.
+  // Only with ONE workgroup per CU: with three (64 channels) an early finisher speeds up its CU mates
+  // and the halves' extra phases cost more than they level (measured 117.0 vs 114.9 us).
   constexpr bool kSplit = MINB == 1;
   const int full = tiles / G, rem = tiles - full * G;
-  int my_n = full + (((full & 1) ? G - 1 - b : b) < rem ? 1 : 0);
-  int i_s = 0, c_s = 0, i_e = 0, c_e = 0, head = 0;   // slice = [(i_s, c_s), (i_e, c_e)) in (position, phase)
-  // Slices only where they pay: a slice at least as long as the heaviest tile (a longer tile would run
-  // as a chain of parts, as slow as the whole tile plus the hand-overs: measured 134 against 121 us on
-  // the Waymo-shaped frame, 173 tiles on 173 workgroups) and fewer than four tiles per workgroup (with
-  // more the snake rounds level within one light tile, and every workgroup gets the same mix of heavy
-  // and light tiles, which the cost scale does not have to get right: B=8, 16 tiles per workgroup).
-  bool slices = false;
-  if constexpr (kSplit) {
-    if (tiles > 0 && tiles < 4 * G) slices = pv.cum[tiles] / G >= pv.cum[1];
-    if (force_slices && tiles > 0) slices = true;   // test hook: chains of three and more parts
-  }
-  if (slices) {
-    __shared__ int s_cut[2];
-    const int total = pv.cum[tiles];
-    const int lo = (int)((long long)total * b / G), hi = (int)((long long)total * (b + 1) / G);
-    if (tid < 2) s_cut[tid] = tiles;
-    __builtin_amdgcn_s_waitcnt(0x0070);
-    __syncthreads();
-    for (int i = tid; i < tiles; i += WAVES * 64) {
-      const int c0 = pv.cum[i], c1 = pv.cum[i + 1];
-      if (c0 <= lo && lo < c1) s_cut[0] = i;
-      if (c0 <= hi && hi < c1) s_cut[1] = i;
-    }
-    __builtin_amdgcn_s_waitcnt(0x0070);
-    __syncthreads();
-    // (position, cost coordinate) -> (position, phases in front of the cut), the same on both sides:
-    // phase p of the header costs 3 popc(block mask) + 4, the cut goes to the nearest boundary
-    auto cut = [&](int i, int x, int &pos, int &c) {
-      pos = tiles;
-      c = 0;
-      if (i >= tiles) return;
-      const int hv = lane < kHdrInts ? pv.hdr[(size_t)pv.sched[i] * kHdrInts + lane] : 0;
-      const int np = __builtin_amdgcn_readlane(hv, 0);
-      const int o = x - pv.cum[i];
-      const bool is_phase = lane >= 1 && lane <= np;
-      const int pc = is_phase ? 3 * __popc((hv >> 5) & 15) + 4 : 0;
-      int incl = pc;
-#pragma unroll
-      for (int d = 1; d < 32; d <<= 1) {
-        const int v = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += v;
-      }
-      const int n = __popcll(__ballot(is_phase && incl - (pc >> 1) <= o));
-      pos = n == np ? i + 1 : i;
-      c = n == np ? 0 : n;
-    };
-    cut(s_cut[0], lo, i_s, c_s);
-    cut(s_cut[1], hi, i_e, c_e);
-    i_s = __builtin_amdgcn_readfirstlane(i_s);
-    c_s = __builtin_amdgcn_readfirstlane(c_s);
-    i_e = __builtin_amdgcn_readfirstlane(i_e);
-    c_e = __builtin_amdgcn_readfirstlane(c_e);
-    if (i_s == i_e) {
-      my_n = c_e > c_s ? 1 : 0;
-    } else {
-      head = c_e > 0 ? 1 : 0;
-      my_n = head + (i_e - i_s);
-    }
-  }
-  // entry i of this workgroup: position in the schedule -> tile | kind << 24; kind bit 0: the part
-  // ends at phase c_e, before the tile does (producer), bit 1: it starts at phase c_s (consumer)
+  const int whole = !kSplit ? rem : (2 * rem > G ? 2 * rem - G : 0);   // leftover tiles dealt whole (the heavier ones)
+  const int last_entries = whole + 2 * (rem - whole);     // = G when rem > G / 2, else 2 * rem
+  const int snake_last = (full & 1) ? G - 1 - b : b;
+  const int my_n = full + (snake_last < last_entries ? 1 : 0);
+  // entry i of this workgroup: tile | owned 16-row blocks << 24
   auto entry = [&](int i) -> int {
-    if (slices) {
-      if (i_s == i_e) return pv.sched[i_s] | ((1 | (c_s > 0 ? 2 : 0)) << 24);
-      if (head) {
-        if (i == 0) return pv.sched[i_e] | (1 << 24);
-        --i;
-      }
-      const int pos = i_e - 1 - i;      // descending: the tile at the bottom of the slice comes last
-      return pv.sched[pos] | ((pos == i_s && c_s > 0 ? 2 : 0) << 24);
-    } else {
-      return pv.sched[(size_t)i * G + ((i & 1) ? G - 1 - b : b)];
-    }
+    if (i < full) return pv.sched[(size_t)i * G + ((i & 1) ? G - 1 - b : b)] | (0xF << 24);
+    if (snake_last < whole) return pv.sched[(size_t)full * G + snake_last] | (0xF << 24);
+    const int h = snake_last - whole;
+    return pv.sched[(size_t)full * G + whole + (h >> 1)] | (((h & 1) ? 0xC : 0x3) << 24);
   };
   if (wg_times && tid == 0) wg_times[b] = wall_clock64();
 
@@ -820,46 +719,20 @@ conv_f32_dma_kernel(const float *__restrict__ feat, unsigned feat_bytes, PlanVie
 
     int gj = 0, ga = 0;
     int hcur = s_hdr[lane & 31], g_tile = __builtin_amdgcn_readfirstlane(s_tiles[0]);
-    // kSplit: the entry's phases are [ga, g_end) of the tile's, padded to kPlanMinPhases (the
-    // look-ahead crosses at most one entry boundary); g_e counts the phases of the entry handed out
-    int g_end = 0, g_cnt = 0, g_e = 0;
-    auto open_entry = [&]() {
-      if constexpr (kSplit) {
-        const int np = __builtin_amdgcn_readlane(hcur, 0);
-        const int kind = (g_tile >> 24) & 3;
-        ga = (kind & 2) ? c_s : 0;
-        g_end = (kind & 1) ? c_e : np;
-        g_cnt = g_end - ga > kPlanMinPhases ? g_end - ga : kPlanMinPhases;
-        g_e = 0;
-      }
-    };
-    open_entry();
     auto next_desc = [&](int &d_tile, int &d_info) {
       d_tile = 0;
       d_info = 0;
       if (gj < cnt) {
         // the plan holds the tile's phases ready made, in execution order (tile_plan_kernel)
+        const int np = __builtin_amdgcn_readlane(hcur, 0);
         d_tile = g_tile;
-        bool done;
-        if constexpr (kSplit) {
-          // offset, block mask and the multiply flag from the plan; first / second / last / valid
-          // by the position inside the entry (the same as the plan's own for a whole tile)
-          const int w = ga < g_end ? __builtin_amdgcn_readlane(hcur, 1 + ga) & 0x3FF : 0;
-          d_info = w | ((16 | (g_e == 0 ? 2 : 0) | (g_e == 1 ? 8 : 0) | (g_e == g_cnt - 1 ? 4 : 0)) << 9);
-          ++ga;
-          done = ++g_e == g_cnt;
-        } else {
-          const int np = __builtin_amdgcn_readlane(hcur, 0);
-          d_info = __builtin_amdgcn_readlane(hcur, 1 + ga);
-          done = ++ga == np;
-        }
-        if (done) {
+        d_info = __builtin_amdgcn_readlane(hcur, 1 + ga);
+        if (++ga == np) {
           ++gj;
           ga = 0;
           if (gj < cnt) {
             hcur = s_hdr[(gj % 3) * kHdrInts + (lane & 31)];
             g_tile = __builtin_amdgcn_readfirstlane(s_tiles[gj]);
-            open_entry();
           }
         }
       }
@@ -885,11 +758,15 @@ conv_f32_dma_kernel(const float *__restrict__ feat, unsigned feat_bytes, PlanVie
 #pragma unroll
         for (int j = 0; j < IPW; ++j) inew[j] = ip[prow[j]];
         // a padding phase fetches row -1: out of range, zeros land in LDS, no fetch.  (An OR with a
-        // scalar mask, not a select: the select became a branch around the first DMA.)
+        // scalar mask, not a select: the select became a branch around the first DMA.)  So do the
+        // rows of 16-row blocks a half tile does not own.
         const unsigned dead = ((iC >> 9) & 1) ? 0u : 0xFFFFFFFFu;
+        const unsigned own = (unsigned)tC >> 24;
 #pragma unroll
-        for (int j = 0; j < IPW; ++j)
-          lds_dma16(rs, nxt2 + (wave * IPW + j) * 1024, ((unsigned)ireg[j] | dead) * ROWB + soff[j]);
+        for (int j = 0; j < IPW; ++j) {
+          const unsigned skip = dead | (((own >> (prow[j] >> 4)) & 1u) - 1u);
+          lds_dma16(rs, nxt2 + (wave * IPW + j) * 1024, ((unsigned)ireg[j] | skip) * ROWB + soff[j]);
+        }
         // compiler fence (no instruction): the memory operations below stay below the DMA, the
         // order kWaitN counts on (tests/test_isa_dma_wait.py checks the emitted ISA)
         asm volatile("" ::: "memory");
@@ -897,39 +774,19 @@ conv_f32_dma_kernel(const float *__restrict__ feat, unsigned feat_bytes, PlanVie
         for (int j = 0; j < IPW; ++j) ireg[j] = inew[j];
       };
       const int fl = iA >> 9;
-      const int part = kSplit ? (tA >> 24) & 3 : 0;
-      int *const handover = const_cast<int *>(pv.hdr) + (size_t)(tA & 0xFFFFFF) * kHdrInts + 30;
-      if (fl & 2) {            // first phase of an entry
+      if (fl & 2) {            // first phase of a tile
         ++cj;
-        if (part & 2) {
-          // the rest of a cut tile: wait for the raw sums of the phases in front of the cut
-          // (bounded: a lost hand-over shows as a wrong result, not as a hung queue)
-          for (int spin = 0; spin < (1 << 20); ++spin) {
-            if (__hip_atomic_load(handover, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == c_s) break;
-            __builtin_amdgcn_s_sleep(16);
-          }
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
 #pragma unroll
         for (int mb = 0; mb < MBW; ++mb) {
           const int e = (tA & 0xFFFFFF) * TM + (rg * MBW + mb) * 16 + ln;
-          orow[mb] = e < n_out ? pv.order[e] : -1;
+          orow[mb] = (e < n_out && (((unsigned)tA >> (24 + rg * MBW + mb)) & 1u)) ? pv.order[e] : -1;
 #pragma unroll
           for (int i = 0; i < NBW; ++i) acc[mb][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        if (part & 2) {
-#pragma unroll
-          for (int mb = 0; mb < MBW; ++mb)
-#pragma unroll
-            for (int i = 0; i < NBW; ++i)
-              if (orow[mb] >= 0)
-                acc[mb][i] = *reinterpret_cast<const f32x4 *>(out + (size_t)orow[mb] * COUT +
-                                                              (cg * NBW + i) * 16 + 4 * g);
         }
         if (tid < kHdrInts && cj + 2 < cnt)
           hreg = pv.hdr[(size_t)(s_tiles[cj + 2] & 0xFFFFFF) * kHdrInts + tid];
       }
-      const int bmw = (fl & 1) ? ((iA >> 5) & 15) >> (rg * MBW) & ((1 << MBW) - 1) : 0;
+      const int bmw = (fl & 1) ? ((iA >> 5) & ((unsigned)tA >> 24) & 15) >> (rg * MBW) & ((1 << MBW) - 1) : 0;
       {
         auto a_at = [&](int mb, int t) {
           const int p = (rg * MBW + mb) * 16 + ln;
@@ -994,23 +851,7 @@ conv_f32_dma_kernel(const float *__restrict__ feat, unsigned feat_bytes, PlanVie
           for (int t = 0; t < T; ++t)
             bf[i][t] = wp[(((size_t)k1 * NB + (cg * NBW + i)) * T + t) * 64 + lane];
       }
-      if ((fl & 4) && (part & 1)) {
-        // end of a part in front of a cut: the raw sums go to the tile's output rows, the next
-        // workgroup picks them up there.  Every wave's stores have reached L2 (full drain), then
-        // one release at agent scope (L2 write-back: the other workgroup sits on another XCD).
-#pragma unroll
-        for (int mb = 0; mb < MBW; ++mb)
-#pragma unroll
-          for (int i = 0; i < NBW; ++i)
-            if (orow[mb] >= 0)
-              *reinterpret_cast<f32x4 *>(out + (size_t)orow[mb] * COUT + (cg * NBW + i) * 16 + 4 * g) =
-                  acc[mb][i];
-        __builtin_amdgcn_s_waitcnt(0x0070);
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(handover, c_e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      } else if (fl & 4) {   // end of a tile: folded BN, residual, ReLU, straight from the accumulators
-        // (the last part of a cut tile re-arms the hand-over word for the next launch over this plan)
-        if ((part & 2) && tid == 0) __hip_atomic_store(handover, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (fl & 4) {   // end of a tile: folded BN, residual, ReLU, straight from the accumulators
         f32x4 sc[NBW], sh[NBW], rsd[MBW][NBW];
 #pragma unroll
         for (int i = 0; i < NBW; ++i) {
@@ -1063,7 +904,6 @@ conv_f32_dma_kernel(const float *__restrict__ feat, unsigned feat_bytes, PlanVie
 unsigned long long *g_ord_prof = nullptr;
 unsigned long long *g_dma_wg_times = nullptr;   // diagnostic only, see sf_debug_dma_wg_times   // diagnostic only, see sf_debug_ordered_profile
 int g_ord_grid_cap = 0;                     // test hook, see sf_debug_ordered_grid_cap (0 = off)
-int g_ord_force_slices = 0;                 // test hook: a negative cap forces the slice schedule
 
 struct OrdArgs {
   const float *feat;
@@ -1086,7 +926,6 @@ PlanView plan_view(const int *plan, int n_bound) {
   v.hdr = v.sched + tiles;
   v.nbrs = v.hdr + (size_t)tiles * kHdrInts;
   v.s_stride = tiles * kTileRows;
-  v.cum = v.nbrs + (size_t)kMaxK * v.s_stride;
   return v;
 }
 
@@ -1123,7 +962,7 @@ int launch_dma(const OrdArgs &a) {
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), 0, a.st, a.feat, a.feat_bytes,
                      plan_view(a.plan, a.n_out_bound), a.K, a.k_first,
                      reinterpret_cast<const f32x4 *>(a.wpk), a.scale, a.shift, a.residual, a.relu,
-                     a.out, a.n_out_dev, a.n_out_bound, g_dma_wg_times, g_ord_force_slices);
+                     a.out, a.n_out_dev, a.n_out_bound, g_dma_wg_times);
   SF_CHECK_LAUNCH();
   return SF_OK;
 }
@@ -1164,7 +1003,7 @@ extern "C" size_t sf_row_order_workspace(int n_bound) {
 extern "C" int sf_row_order_size(int n_bound) {
   if (n_bound < 1) n_bound = 1;
   const long long tiles = plan_tiles(n_bound);
-  const long long ints = (long long)n_bound + tiles + tiles * kHdrInts + 27ll * tiles * kTileRows + tiles + 1;
+  const long long ints = (long long)n_bound + tiles + tiles * kHdrInts + 27ll * tiles * kTileRows;
   return ints < 0x7FFFFFFFll ? (int)ints : -1;   // -1: more than 2^31 ints (n_bound beyond ~75 M rows)
 }
 
@@ -1230,7 +1069,7 @@ int sf_int_row_order(const int *nbr, int nbr_stride, int K, int k_first, const i
                      const_cast<int *>(pv.nbrs), pv.s_stride);
   SF_CHECK_LAUNCH();
   hipLaunchKernelGGL(tile_schedule_kernel, dim3(1), dim3(1024), 0, st, pv.hdr, n_dev, n_bound,
-                     const_cast<int *>(pv.sched), const_cast<int *>(pv.cum));
+                     const_cast<int *>(pv.sched));
   SF_CHECK_LAUNCH();
   return SF_OK;
 }
@@ -1252,9 +1091,6 @@ extern "C" int sf_sparse_conv_f32_ordered(const float *features_in, int n_in_bou
                    ((uintptr_t)w_packed & 15) == 0 && ((uintptr_t)residual & 15) == 0 &&
                    ((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0,
                "feature / filter / epilogue pointers must be 16-byte aligned");
-  // (a tile split between two workgroups parks its raw sums in its output rows)
-  SF_CHECK_ARG((const float *)out != features_in && (const float *)out != residual,
-               "out must not alias features_in or residual");
   const long long bytes = (long long)n_in_bound * cin_padded * 4;
   SF_CHECK_ARG(n_in_bound >= 1 && bytes < (1ll << 32) - 4096,
                "the input feature table (%d rows) must stay below 4 GiB", n_in_bound);
@@ -1287,10 +1123,7 @@ extern "C" __attribute__((visibility("default"))) void sf_debug_dma_wg_times(voi
 
 // Test hook (not part of the documented ABI): limits the grid of the ordered / DMA kernels to `cap`
 // persistent workgroups (0 = off), so that a small problem gives a workgroup more than kRun tiles
-// (tests/test_gpu_conv_ordered.py::test_many_tiles_per_workgroup).  A NEGATIVE cap limits the grid to
-// -cap and makes the 128-channel DMA kernel use its slice schedule whatever the tile count (a slice
-// shorter than a tile: chains of three and more parts).  Process-wide, not thread-safe.
+// (tests/test_gpu_conv_ordered.py::test_many_tiles_per_workgroup).  Process-wide, not thread-safe.
 extern "C" __attribute__((visibility("default"))) void sf_debug_ordered_grid_cap(int cap) {
-  g_ord_grid_cap = cap > 0 ? cap : (cap < 0 ? -cap : 0);
-  g_ord_force_slices = cap < 0;
+  g_ord_grid_cap = cap > 0 ? cap : 0;
 }

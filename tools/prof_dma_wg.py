@@ -86,14 +86,8 @@ def main():
         sched = plan[n_bound:n_bound + tiles_b]
         hdr = plan[n_bound + tiles_b:n_bound + tiles_b + 32 * tiles_b].reshape(tiles_b, 32)
         nact_t = np.array([bin(int(m) & 0x7FFFFFF).count('1') for m in hdr[:, 29]])
+        prod_t = hdr[:, 28] - 3 * nact_t
         ph_t = hdr[:, 0]                 # phases incl. padding
-        prod_t = (hdr[:, 28] - 4 * ph_t) // 3
-        if '128, 128' in kern:
-            # slices of the running cost sum, tiles cut by phases: no per-workgroup tile list to fit
-            print(f'    plan: products per workgroup mean {prod_t[sched[:tiles]].sum() / g:.1f}, phases mean '
-                  f'{ph_t[sched[:tiles]].sum() / g:.1f}; cost slice {hdr[sched[:tiles], 28].sum() / g:.0f}, '
-                  f'heaviest tile {hdr[sched[0], 28]}')
-            continue
         wp, wph = np.zeros(g), np.zeros(g)
         for i in range((tiles + g - 1) // g):
             for b in range(g):
