@@ -81,8 +81,10 @@ def main():
         from sparsefusion_amd import _lib
         raw = ctypes.CDLL(_lib.LIB_PATH)
         raw.sf_debug_dma_wg_times.argtypes = [ctypes.c_void_p]
-        wg_buf = torch.zeros(2 * 4096, dtype=torch.int64, device=dev)
-        raw.sf_debug_dma_wg_times(wg_buf.data_ptr())
+        # one stamp buffer per captured graph (lane x frame): a replay overwrites the stamps of the graph's
+        # earlier replays, the last 128->128 launch of the graph wins -- most graphs are replayed last in
+        # mid-pipeline, only the final few while the pipeline drains
+        wg_buf = torch.zeros(args.lanes * args.distinct, 2 * 4096, dtype=torch.int64, device=dev)
     if args.ordered_grid_cap:
         import ctypes
         from sparsefusion_amd import _lib
@@ -94,7 +96,14 @@ def main():
         for li, lane in enumerate(lanes):
             light = (l0, l1)[li % 2]
             w_ = wide1 if (args.wide_streams == 2 and li % 2) else wide
-            sfs.append([lane.capture_split(f, [light, light, w_]) for f in frames])
+            row = []
+            for fi, f in enumerate(frames):
+                if wg_buf is not None:
+                    raw.sf_debug_dma_wg_times(wg_buf[li * args.distinct + fi].data_ptr())
+                row.append(lane.capture_split(f, [light, light, w_]))
+            sfs.append(row)
+    if wg_buf is not None:
+        raw.sf_debug_dma_wg_times(None)
     torch.cuda.synchronize()
 
     base = torch.cuda.Event(enable_timing=True)
@@ -138,14 +147,15 @@ def main():
         print(f'round {rnd}: host submit {1e3 * (t1 - t0):.2f} ms, all done {1e3 * (t2 - t0):.2f} ms '
               f'= {1e3 * (t2 - t0) / args.frames:.3f} ms/frame')
     if wg_buf is not None:
-        v = wg_buf.cpu().numpy()
         g = 256
-        st, en = v[:g].astype(np.float64), v[g:2 * g].astype(np.float64)
-        t0 = st.min()
-        endr, busy = (en - t0) / 100.0, (en - st) / 100.0
-        print(f'last 128->128 launch inside the pipeline: span {endr.max():.1f} us | start spread {(st.max() - t0) / 100:.1f} us | '
-              f'workgroup ends p10 {np.percentile(endr, 10):.1f} p50 {np.percentile(endr, 50):.1f} p90 {np.percentile(endr, 90):.1f} '
-              f'max {endr.max():.1f} | busy mean {busy.mean():.1f} min {busy.min():.1f} max {busy.max():.1f} us = {busy.mean() / endr.max():.1%} of the span')
+        for gi, v in enumerate(wg_buf.cpu().numpy()):
+            st, en = v[:g].astype(np.float64), v[g:2 * g].astype(np.float64)
+            t0 = st.min()
+            endr, busy, startr = (en - t0) / 100.0, (en - st) / 100.0, (st - t0) / 100.0
+            print(f'lane {gi // args.distinct} frame {gi % args.distinct}: last 128->128 launch of the graph: span {endr.max():6.1f} us | '
+                  f'starts p50 {np.percentile(startr, 50):5.1f} p90 {np.percentile(startr, 90):5.1f} max {startr.max():5.1f} | '
+                  f'ends p10 {np.percentile(endr, 10):6.1f} p50 {np.percentile(endr, 50):6.1f} max {endr.max():6.1f} | '
+                  f'busy mean {busy.mean():6.1f} max {busy.max():6.1f} us = {busy.mean() / endr.max():.1%} of the span')
     if args.quiet:
         return
     print('frame: host submit [ms from t0] (wait_event, replay calls) | light seg GPU start..end | wide seg GPU start..end')
